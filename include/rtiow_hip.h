@@ -1,0 +1,227 @@
+/*
+ * rtiow_hip.h -- C ABI of the MI355X (gfx950) path-tracer core.
+ *
+ * The reference application has no plugin/FFI layer; its seam is the abstract
+ * class `Raytracer` (R/src/Core/Raytracer.h:24-49: ctor(img, Scene&, H, W, spp,
+ * maxDepth, buildUp), Run(), Cancel()) that `runRaytracer()` instantiates
+ * (R/src/RaytracingApplication.cpp:260-269), and the per-frame compute dispatch
+ * of the GPU toggle (R/src/RaytracingApplication.cpp:198-208).  Every entry point
+ * below names the reference code it replaces.  R/ = Raytracing-In-A-Weekend/.
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 on success
+ * and a negative rt_status on failure (rt_last_error() gives the text); nothing
+ * throws across the boundary; the library copies what it needs during the call and
+ * never frees caller memory.  A scene handle is host-only and needs no GPU.  A
+ * context owns one device and one stream; calls on one context are not re-entrant,
+ * except rt_cancel(), which may be called from any thread.
+ */
+#ifndef RTIOW_HIP_H
+#define RTIOW_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rt_scene rt_scene;     /* host-side scene under construction  */
+typedef struct rt_context rt_context; /* one device + one stream + buffers   */
+
+typedef enum rt_status {
+    RT_OK = 0,
+    RT_ERR_INVALID = -1,   /* bad argument / handle / index            */
+    RT_ERR_NO_DEVICE = -2, /* no usable HIP device (the path never falls back to the CPU) */
+    RT_ERR_HIP = -3,       /* a HIP runtime call failed                */
+    RT_ERR_STATE = -4,     /* call made in the wrong order             */
+    RT_ERR_CANCELLED = -5, /* rt_cancel() interrupted the render       */
+    RT_ERR_LIMIT = -6      /* size beyond a documented maximum         */
+} rt_status;
+
+/* Material kinds: R/src/Material/Material.h:17-170 */
+enum {
+    RT_MAT_LAMBERTIAN = 0, /* Material.h:17-40   */
+    RT_MAT_METAL = 1,      /* Material.h:42-58   */
+    RT_MAT_DIELECTRIC = 2, /* Material.h:60-96   */
+    RT_MAT_LIGHT = 3,      /* Material.h:98-114  */
+    RT_MAT_PBR = 4         /* Material.h:116-170 */
+};
+
+const char* rt_last_error(void);
+const char* rt_version(void);
+
+/* ------------------------------------------------------------------ scene (host) */
+
+/* New empty scene: an empty world list (R/src/Core/Raytracer.h:17-22 `Scene`) plus a
+ * default-seeded mt19937 that every later build step draws from in program order, as
+ * the reference's process-global generator does (R/src/Core/RTWeekend.h:26-31). */
+int rt_scene_create(rt_scene** out);
+void rt_scene_destroy(rt_scene* s);
+
+/* Next n values of the scene's generator, exactly as randomFloat() returns them
+ * (R/src/Core/RTWeekend.h:26-31).  Advances the stream. */
+int rt_scene_rng_floats(rt_scene* s, int n, float* out);
+
+/* Lambertian(a) / Metal(a, fuzz) / Dielectric(ir) / DiffuseLight(emit) constructors
+ * (R/src/Material/Material.h:20,45,63,101).  Returns the material index (>= 0). */
+int rt_scene_add_material(rt_scene* s, int kind, float r, float g, float b, float param);
+/* Texture(path) after decoding: tightly packed RGB8, row 0 first (R/src/Material/Texture.h:7-29;
+ * the 8-bit -> float map of stbi_loadf, R/vendor/stb_image/stb_image.h:1840-1861, is applied
+ * by the library).  Returns the texture index. */
+int rt_scene_add_texture_rgb8(rt_scene* s, int width, int height, const uint8_t* rgb);
+/* PBRMaterial(diffuse) + setRoughnessTexture + setNormalTexture (Material.h:119,162-163);
+ * pass -1 for an absent texture.  Returns the material index. */
+int rt_scene_add_material_pbr(rt_scene* s, int tex_diffuse, int tex_roughness, int tex_normal);
+
+/* world.add(make_shared<Sphere>(center, radius, material))  (R/src/Core/Hittable.h:226).
+ * Returns the sphere id (creation order). */
+int rt_scene_add_sphere(rt_scene* s, float cx, float cy, float cz, float radius, int material);
+/* world.add(make_shared<Triangle>(v0, v1, v2, ...))  (R/src/Core/Hittable.h:50-56).
+ * pos[9]; normal[9] (first normal all zero = geometric normal, Hittable.h:89-92);
+ * uv[6] (uv[0] == -1 = use barycentrics, Hittable.h:97-107).  Returns the triangle id. */
+int rt_scene_add_triangle(rt_scene* s, const float* pos9, const float* normal9, const float* uv6, int material);
+/* world.add(make_shared<Box>(p0, p1, material, model))  (R/src/Core/Hittable.h:318-385):
+ * twelve triangles in the reference's order.  model16 is column-major. */
+int rt_scene_add_box(rt_scene* s, const float* p0, const float* p1, int material, const float* model16);
+/* world.add(make_shared<Mesh>(model, file)) with the importer's output handed in as arrays
+ * (R/src/Core/Mesh.cpp:7-37,106-208): per-face Triangle creation with the model-matrix
+ * transform, mesh AABB, and BVHNode(triangles, 0, n, max_depth) built on the scene's
+ * generator (the reference passes max_depth = 10).  normals / uvs may be NULL.
+ * indices: 3 per triangle.  Returns the id of the mesh's first triangle. */
+int rt_scene_add_mesh(rt_scene* s, const float* model16, int n_vertices, const float* positions, const float* normals,
+                      const float* uvs, int n_triangles, const uint32_t* indices, int material, int max_depth);
+/* Reads a glTF 2.0 file (+ external .bin) with one mesh primitive and adds it as above
+ * (the part of Assimp::Importer::ReadFile that R/src/Core/Mesh.cpp:10-12 relies on).
+ * Texture images are not decoded here; bind them through `material`. */
+int rt_scene_add_mesh_gltf(rt_scene* s, const float* model16, const char* gltf_path, int material, int max_depth);
+
+/* world = randomScene()  (R/src/RaytracingApplication.cpp:359-405), drawn in g++ argument order. */
+int rt_scene_random_scene(rt_scene* s);
+/* world = cornellBox()   (R/src/RaytracingApplication.cpp:407-478). */
+int rt_scene_cornell_box(rt_scene* s);
+/* world = HittableList(make_shared<BVHNode>(world))  (R/src/AccelerationStructures/Bvh.h:17-78). */
+int rt_scene_wrap_bvh(rt_scene* s);
+
+/* Camera(lookfrom, lookat, vup, vfov, aspectRatio, aperture, focusDist)  (R/src/Core/Camera.h:7-25). */
+int rt_scene_set_camera(rt_scene* s, const float* lookfrom3, const float* lookat3, const float* vup3, float vfov,
+                        float aspect_ratio, float aperture, float focus_dist);
+/* The eight camera members in the order the reference uploads them as uniforms
+ * (R/src/RaytracingApplication.cpp:140-147): origin, lowerLeftCorner, horizontal, vertical,
+ * u, v, w (3 floats each), lensRadius. */
+int rt_scene_get_camera(const rt_scene* s, float* out22);
+int rt_scene_set_background(rt_scene* s, float r, float g, float b); /* Scene::background */
+
+/* ------------------------------------------------- flattened scene (host, for inspection) */
+
+typedef struct rt_flat_info {
+    int n_nodes;      /* threaded BVH entries, reference pre-order              */
+    int n_prim_refs;  /* leaf references in reference visit order               */
+    int n_spheres;
+    int n_triangles;
+    int n_materials;
+    int n_textures;
+    int max_leaf;     /* longest run of primitives under one entry              */
+    int fits_lds;     /* 1 if the traversal data fits the LDS-resident kernel   */
+} rt_flat_info;
+
+/* Flattens the world (the BVH flatten step): packed node array in the reference's
+ * pre-order (BVHNode::Hit's left-then-right order, Bvh.h:80-88), leaf references in visit
+ * order.  Idempotent; called implicitly by rt_upload_scene(). */
+int rt_scene_flatten(rt_scene* s, rt_flat_info* info);
+/* Copies of the flattened arrays.  nodes: 8 x 32-bit words per entry
+ * {min.x, min.y, min.z, skip | flags, max.x, max.y, max.z, first_ref};
+ * flag bit 30 of word 3 = entry has no box test (a HittableList, Hittable.h:281-296).
+ * prim_refs: bit 31 = last of its leaf, bit 30 = triangle, low bits = id.  Any pointer may be NULL. */
+int rt_scene_get_flat(const rt_scene* s, uint32_t* nodes8, uint32_t* prim_refs, float* spheres4, int32_t* sphere_mat,
+                      float* tri_pos9, float* tri_normal9, float* tri_uv6, int32_t* tri_mat, int32_t* mat_kind,
+                      float* mat_rgbp4);
+
+/* ------------------------------------------------------------------ device */
+
+int rt_device_count(void);
+/* Opens device `device` (hipSetDevice) and creates the context's stream. */
+int rt_create(int device, rt_context** out);
+void rt_destroy(rt_context* ctx);
+
+/* Copies the flattened scene, camera and background to the device (replaces what
+ * `Raytracer`'s constructor captures from Scene&, Raytracer.h:27-31). */
+int rt_upload_scene(rt_context* ctx, rt_scene* s);
+
+/* Image size and the share of it this context renders.  The image is cut into 8x8-pixel
+ * tiles; tile (tx, ty) belongs to rank (tx + ty) mod world.  Allocates and zeroes the
+ * accumulation buffer (mOrigColorData, Raytracer.h:28-31).  rank 0 / world 1 = whole image. */
+int rt_set_target(rt_context* ctx, int width, int height, int rank, int world);
+/* Same, but the accumulation buffer is caller-owned device memory of rt_accum_bytes() bytes
+ * (256-byte aligned), e.g. a tensor that a collective library will read.  Not zeroed. */
+int rt_set_target_external(rt_context* ctx, int width, int height, int rank, int world, void* device_accum);
+size_t rt_accum_bytes(int width, int height, int world);
+
+/* Zeroes the accumulation buffer (the memset of Raytracer.h:30). */
+int rt_clear(rt_context* ctx);
+
+/* Adds samples [first_sample, first_sample + n_samples) of every owned pixel to the
+ * accumulation buffer: the pixel loops of RaytracerNormal::Run / RaytracerMT::writeLine
+ * (R/src/Core/Raytracer.cpp:46-132) with rayColor (Raytracer.cpp:3-20) for each sample.
+ * Random numbers are the reference shader's stateless hash keyed (x, y, sample, counter)
+ * (R/assets/shaders/raytracer.comp:35-54).  Asynchronous on the context's stream. */
+int rt_render(rt_context* ctx, int first_sample, int n_samples, int max_depth);
+/* Blocks until the stream is idle (the join in runRaytracer(), RaytracingApplication.cpp:269). */
+int rt_sync(rt_context* ctx);
+/* Raytracer::Cancel() (Raytracer.h:59-62,77-80): makes a running rt_run() stop at the next
+ * pass boundary.  Thread-safe. */
+int rt_cancel(rt_context* ctx);
+
+/* Complete progressive render: passes of `samples_per_pass` until `samples_per_pixel` are
+ * done or rt_cancel() is called; after each pass `on_pass(done, user)` may be invoked
+ * (NULL = no callback).  Stands in for Raytracer::Run() (Raytracer.cpp:46-95,134-194). */
+typedef void (*rt_pass_callback)(int samples_done, void* user);
+int rt_run(rt_context* ctx, int samples_per_pixel, int samples_per_pass, int max_depth, rt_pass_callback on_pass,
+           void* user);
+
+/* Row-major W*H*4 float sums (alpha = 1), row 0 = bottom of the image: the RGBA32F image
+ * the GPU toggle binds (RaytracingApplication.cpp:132-133).  Pixels of other ranks are 0
+ * unless rt_resolve_gathered() was used.  Blocking. */
+int rt_read_accum_rgba32f(rt_context* ctx, float* dst);
+/* writeColor()'s bytes (Raytracer.cpp:22-44): 256 * clamp(sqrt(sum / samples_per_pixel), 0, 0.999),
+ * A = 255, row 0 = bottom: the buffer glTexImage2D uploads (RaytracingApplication.cpp:194). */
+int rt_read_rgba8(rt_context* ctx, int samples_per_pixel, uint8_t* dst);
+
+/* Device-side resolve of `world` rank payloads laid end to end (the output of an all-gather
+ * of every rank's accumulation buffer) into a row-major RGBA32F device image. */
+int rt_resolve_gathered(rt_context* ctx, const void* device_payloads, int world, void* device_rgba32f);
+
+/* Test hook: closest hit of n rays (origin xyz, direction xyz) with tMin = 0.001, as
+ * mWorld.Hit(r, 0.001f, infinity, rec) (Raytracer.cpp:10).  prim_kind: -1 miss, 0 sphere,
+ * 1 triangle.  Optional outputs may be NULL.  Host pointers; blocking. */
+int rt_trace(rt_context* ctx, int n, const float* rays6, int32_t* prim_kind, int32_t* prim_id, float* t, float* normal3,
+             int32_t* front_face, float* uv2);
+
+/* Test hook: n independent Material::scatter() calls (R/src/Material/Material.h:22-160) with the
+ * hit record handed in: material index, incoming ray, hit point, shading normal, frontFace,
+ * (u, v), and the RNG position key4 = {pixel x, pixel y, sample, counter before the call}.
+ * Outputs: attenuation, scattered ray, alive flag (scatter()'s return value) and the RNG
+ * counter after the call.  Host pointers; blocking. */
+int rt_scatter_test(rt_context* ctx, int n, const int32_t* material, const float* ray_in6, const float* p3,
+                    const float* normal3, const int32_t* front_face, const float* uv2, const uint32_t* key4,
+                    float* atten3, float* ray_out6, int32_t* alive, uint32_t* counter_out);
+
+/* Path statistics of one counting pass over the owned pixels (same paths as rt_render):
+ * samples, rays, node tests, sphere tests, triangle tests, hits, scatters by material kind
+ * (lambertian, metal, dielectric, light, pbr), misses, depth cut-offs.  Blocking. */
+typedef struct rt_counters {
+    uint64_t samples, rays, node_tests, sphere_tests, tri_tests, hits;
+    uint64_t scatter_lambertian, scatter_metal, scatter_dielectric, scatter_light, scatter_pbr;
+    uint64_t misses, depth_cutoffs;
+} rt_counters;
+int rt_count(rt_context* ctx, int first_sample, int n_samples, int max_depth, rt_counters* out);
+
+/* Milliseconds the last rt_render() kernel took on the device (HIP events on the context's
+ * stream).  Blocks until that kernel has finished. */
+int rt_last_render_ms(rt_context* ctx, float* ms);
+/* The context's hipStream_t, for callers that order their own work after rt_render(). */
+void* rt_stream(rt_context* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTIOW_HIP_H */

@@ -1,0 +1,762 @@
+// Host-side scene construction, reference-order BVH build and the flatten step.
+// All arithmetic is IEEE binary32 evaluated in the order the reference's expressions
+// evaluate (compile with -ffp-contract=off).  glm is not available to check against;
+// the operation orders used for dot / cross / normalize / mat4*vec4 / inverse are glm
+// 0.9.9's scalar code paths as commonly documented.
+// R/ = /root/reference/Raytracing-In-A-Weekend/.
+#include "host_scene.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <limits>
+#include <map>
+#include <memory>
+#include <sstream>
+
+namespace rt {
+
+namespace {
+
+const float kInf = std::numeric_limits<float>::infinity();
+
+inline float dot3(const float* a, const float* b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
+inline void cross3(const float* a, const float* b, float* o) {
+    float x = a[1] * b[2] - b[1] * a[2];
+    float y = a[2] * b[0] - b[2] * a[0];
+    float z = a[0] * b[1] - b[0] * a[1];
+    o[0] = x;
+    o[1] = y;
+    o[2] = z;
+}
+inline void normalize3(const float* v, float* o) {
+    float inv = 1.0f / std::sqrt(dot3(v, v));
+    o[0] = v[0] * inv;
+    o[1] = v[1] * inv;
+    o[2] = v[2] * inv;
+}
+
+// Column-major 4x4 helpers: m[col*4 + row].
+inline void mulPoint(const float* m, const float* p, float w, float* out3) {
+    for (int r = 0; r < 3; r++) {
+        float a = m[0 * 4 + r] * p[0], b = m[1 * 4 + r] * p[1];
+        float c = m[2 * 4 + r] * p[2], d = m[3 * 4 + r] * w;
+        out3[r] = (a + b) + (c + d);
+    }
+}
+
+// Inverse by cofactors scaled with the reciprocal determinant (glm::inverse for mat4).
+void inverse4(const float* src, float* dst) {
+    auto m = [&](int c, int r) { return src[c * 4 + r]; };
+    float c00 = m(2, 2) * m(3, 3) - m(3, 2) * m(2, 3);
+    float c02 = m(1, 2) * m(3, 3) - m(3, 2) * m(1, 3);
+    float c03 = m(1, 2) * m(2, 3) - m(2, 2) * m(1, 3);
+    float c04 = m(2, 1) * m(3, 3) - m(3, 1) * m(2, 3);
+    float c06 = m(1, 1) * m(3, 3) - m(3, 1) * m(1, 3);
+    float c07 = m(1, 1) * m(2, 3) - m(2, 1) * m(1, 3);
+    float c08 = m(2, 1) * m(3, 2) - m(3, 1) * m(2, 2);
+    float c10 = m(1, 1) * m(3, 2) - m(3, 1) * m(1, 2);
+    float c11 = m(1, 1) * m(2, 2) - m(2, 1) * m(1, 2);
+    float c12 = m(2, 0) * m(3, 3) - m(3, 0) * m(2, 3);
+    float c14 = m(1, 0) * m(3, 3) - m(3, 0) * m(1, 3);
+    float c15 = m(1, 0) * m(2, 3) - m(2, 0) * m(1, 3);
+    float c16 = m(2, 0) * m(3, 2) - m(3, 0) * m(2, 2);
+    float c18 = m(1, 0) * m(3, 2) - m(3, 0) * m(1, 2);
+    float c19 = m(1, 0) * m(2, 2) - m(2, 0) * m(1, 2);
+    float c20 = m(2, 0) * m(3, 1) - m(3, 0) * m(2, 1);
+    float c22 = m(1, 0) * m(3, 1) - m(3, 0) * m(1, 1);
+    float c23 = m(1, 0) * m(2, 1) - m(2, 0) * m(1, 1);
+    const float f0[4] = {c00, c00, c02, c03}, f1[4] = {c04, c04, c06, c07}, f2[4] = {c08, c08, c10, c11};
+    const float f3[4] = {c12, c12, c14, c15}, f4[4] = {c16, c16, c18, c19}, f5[4] = {c20, c20, c22, c23};
+    const float v0[4] = {m(1, 0), m(0, 0), m(0, 0), m(0, 0)}, v1[4] = {m(1, 1), m(0, 1), m(0, 1), m(0, 1)};
+    const float v2[4] = {m(1, 2), m(0, 2), m(0, 2), m(0, 2)}, v3[4] = {m(1, 3), m(0, 3), m(0, 3), m(0, 3)};
+    const float sa[4] = {+1, -1, +1, -1}, sb[4] = {-1, +1, -1, +1};
+    for (int i = 0; i < 4; i++) {
+        dst[0 * 4 + i] = ((v1[i] * f0[i] - v2[i] * f1[i]) + v3[i] * f2[i]) * sa[i];
+        dst[1 * 4 + i] = ((v0[i] * f0[i] - v2[i] * f3[i]) + v3[i] * f4[i]) * sb[i];
+        dst[2 * 4 + i] = ((v0[i] * f1[i] - v1[i] * f3[i]) + v3[i] * f5[i]) * sa[i];
+        dst[3 * 4 + i] = ((v0[i] * f2[i] - v1[i] * f4[i]) + v2[i] * f5[i]) * sb[i];
+    }
+    float det = (src[0] * dst[0 * 4 + 0] + src[1] * dst[1 * 4 + 0]) + (src[2] * dst[2 * 4 + 0] + src[3] * dst[3 * 4 + 0]);
+    float ood = 1.0f / det;
+    for (int i = 0; i < 16; i++) dst[i] = dst[i] * ood;
+}
+
+inline Box3 unionBox(const Box3& a, const Box3& b) {  // surroundingBox, R/src/AccelerationStructures/AABB.cpp:3-12
+    Box3 o;
+    for (int k = 0; k < 3; k++) {
+        o.mn[k] = std::fmin(a.mn[k], b.mn[k]);
+        o.mx[k] = std::fmax(a.mx[k], b.mx[k]);
+    }
+    return o;
+}
+
+// Triangle::BoundingBox, R/src/Core/Hittable.h:143-213: the maximum starts at 1e-8 (not -inf)
+// and an axis with min == max is widened by one unit each way.
+Box3 triangleBox(const HostTriangle& t) {
+    Box3 b;
+    for (int a = 0; a < 3; a++) {
+        float mn = kInf, mx = 1e-8f;
+        for (int k = 0; k < 3; k++)
+            if (t.pos[3 * k + a] < mn) mn = t.pos[3 * k + a];
+        for (int k = 0; k < 3; k++)
+            if (t.pos[3 * k + a] > mx) mx = t.pos[3 * k + a];
+        if (mn == mx) {
+            mn--;
+            mx++;
+        }
+        b.mn[a] = mn;
+        b.mx[a] = mx;
+    }
+    return b;
+}
+
+inline uint32_t bitsOf(float f) {
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    return u;
+}
+
+// ---------------------------------------------------------------- minimal JSON (glTF) reader
+struct JValue {
+    enum T { NUL, BOOL, NUM, STR, ARR, OBJ } t = NUL;
+    double num = 0;
+    bool b = false;
+    std::string str;
+    std::vector<JValue> arr;
+    std::map<std::string, JValue> obj;
+    const JValue* get(const char* k) const {
+        auto it = obj.find(k);
+        return it == obj.end() ? nullptr : &it->second;
+    }
+};
+struct JParser {
+    const std::string& s;
+    size_t i = 0;
+    bool ok = true;
+    explicit JParser(const std::string& src) : s(src) {}
+    void ws() {
+        while (i < s.size() && (s[i] == ' ' || s[i] == '\n' || s[i] == '\t' || s[i] == '\r')) i++;
+    }
+    JValue parse() {
+        ws();
+        JValue v;
+        if (i >= s.size()) {
+            ok = false;
+            return v;
+        }
+        char c = s[i];
+        if (c == '{') {
+            v.t = JValue::OBJ;
+            i++;
+            ws();
+            if (i < s.size() && s[i] == '}') {
+                i++;
+                return v;
+            }
+            while (ok) {
+                ws();
+                JValue k = parse();
+                if (k.t != JValue::STR) {
+                    ok = false;
+                    break;
+                }
+                ws();
+                if (i >= s.size() || s[i] != ':') {
+                    ok = false;
+                    break;
+                }
+                i++;
+                v.obj[k.str] = parse();
+                ws();
+                if (i < s.size() && s[i] == ',') {
+                    i++;
+                    continue;
+                }
+                if (i < s.size() && s[i] == '}') {
+                    i++;
+                    break;
+                }
+                ok = false;
+            }
+        } else if (c == '[') {
+            v.t = JValue::ARR;
+            i++;
+            ws();
+            if (i < s.size() && s[i] == ']') {
+                i++;
+                return v;
+            }
+            while (ok) {
+                v.arr.push_back(parse());
+                ws();
+                if (i < s.size() && s[i] == ',') {
+                    i++;
+                    continue;
+                }
+                if (i < s.size() && s[i] == ']') {
+                    i++;
+                    break;
+                }
+                ok = false;
+            }
+        } else if (c == '"') {
+            v.t = JValue::STR;
+            i++;
+            while (i < s.size() && s[i] != '"') {
+                if (s[i] == '\\' && i + 1 < s.size()) {
+                    i++;
+                    char e = s[i];
+                    v.str += (e == 'n' ? '\n' : e == 't' ? '\t' : e);
+                } else {
+                    v.str += s[i];
+                }
+                i++;
+            }
+            if (i >= s.size()) ok = false;
+            i++;
+        } else if (c == 't' && s.compare(i, 4, "true") == 0) {
+            v.t = JValue::BOOL;
+            v.b = true;
+            i += 4;
+        } else if (c == 'f' && s.compare(i, 5, "false") == 0) {
+            v.t = JValue::BOOL;
+            i += 5;
+        } else if (c == 'n' && s.compare(i, 4, "null") == 0) {
+            i += 4;
+        } else {
+            size_t j = i;
+            while (j < s.size() && (std::isdigit((unsigned char)s[j]) || s[j] == '-' || s[j] == '+' || s[j] == '.' ||
+                                    s[j] == 'e' || s[j] == 'E'))
+                j++;
+            if (j == i) {
+                ok = false;
+                return v;
+            }
+            v.t = JValue::NUM;
+            v.num = std::strtod(s.substr(i, j - i).c_str(), nullptr);
+            i = j;
+        }
+        return v;
+    }
+};
+
+bool readFile(const std::string& path, std::string* out) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) return false;
+    std::ostringstream ss;
+    ss << f.rdbuf();
+    *out = ss.str();
+    return true;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------- RNG
+Scene::Scene() : gen_() {}  // std::mt19937 default seed 5489, as `static std::mt19937 generator;`
+
+// uniform_real_distribution<float>(0,1) over mt19937 in libstdc++ is one 32-bit draw scaled
+// by 2^-32 in float, with results that round up to 1 replaced by the float just below 1
+// (R/src/Core/RTWeekend.h:26-31).
+float Scene::randomFloat() {
+    uint32_t r = (uint32_t)gen_();
+    float sum = (float)r;             // rounds to 24 bits
+    float ret = sum / 4294967296.0f;  // exact scaling
+    if (ret >= 1.0f) ret = std::nextafter(1.0f, 0.0f);
+    return ret;
+}
+// randomVec(): the three constructor arguments are evaluated right to left by g++, the
+// compiler that defines the canonical scene: z first (R/src/Core/RTWeekend.h:45-53).
+void Scene::randomVec(float out[3]) {
+    out[2] = randomFloat();
+    out[1] = randomFloat();
+    out[0] = randomFloat();
+}
+void Scene::randomVec(float mn, float mx, float out[3]) {
+    out[2] = randomFloat(mn, mx);
+    out[1] = randomFloat(mn, mx);
+    out[0] = randomFloat(mn, mx);
+}
+
+// ---------------------------------------------------------------------------- building blocks
+int Scene::addMaterial(int kind, float r, float g, float b, float param) {
+    if (kind == 1) param = param < 1 ? param : 1;  // Metal clamps fuzz, R/src/Material/Material.h:45
+    materials.push_back({kind, r, g, b, param, -1, -1, -1});
+    flat.valid = false;
+    return (int)materials.size() - 1;
+}
+int Scene::addTexture(int w, int h, const uint8_t* rgb) {
+    HostTexture t;
+    t.w = w;
+    t.h = h;
+    t.rgb.assign(rgb, rgb + (size_t)w * h * 3);
+    textures.push_back(std::move(t));
+    flat.valid = false;
+    return (int)textures.size() - 1;
+}
+int Scene::addPbr(int td, int tr, int tn) {
+    materials.push_back({4, 0, 0, 0, 0, td, tr, tn});
+    flat.valid = false;
+    return (int)materials.size() - 1;
+}
+int Scene::addSphere(float cx, float cy, float cz, float r, int mat) {
+    spheres.push_back({{cx, cy, cz}, r, mat});
+    world.push_back({Obj::SPHERE, (int)spheres.size() - 1});
+    flat.valid = false;
+    return (int)spheres.size() - 1;
+}
+int Scene::newTriangle(const float* pos9, const float* nrm9, const float* uv6, int mat) {
+    HostTriangle t;
+    std::memcpy(t.pos, pos9, sizeof t.pos);
+    std::memcpy(t.nrm, nrm9, sizeof t.nrm);
+    std::memcpy(t.uv, uv6, sizeof t.uv);
+    t.mat = mat;
+    triangles.push_back(t);
+    flat.valid = false;
+    return (int)triangles.size() - 1;
+}
+int Scene::addTriangle(const float* pos9, const float* nrm9, const float* uv6, int mat) {
+    int id = newTriangle(pos9, nrm9, uv6, mat);
+    world.push_back({Obj::TRIANGLE, id});
+    return id;
+}
+
+// Box::Box, R/src/Core/Hittable.h:322-385: twelve triangles with zero normals from the eight
+// transformed corners, in the reference's order.  Box::BoundingBox is (p0, p1) untransformed.
+int Scene::addBox(const float* p0, const float* p1, int mat, const float* model16) {
+    // corner selector per vertex: 0 takes the coordinate from p0, 1 from p1
+    static const int sel[12][3][3] = {
+        {{0, 0, 0}, {0, 0, 1}, {0, 1, 0}}, {{0, 0, 1}, {0, 1, 1}, {0, 1, 0}},  // left
+        {{1, 0, 0}, {1, 0, 1}, {1, 1, 0}}, {{1, 0, 1}, {1, 1, 1}, {1, 1, 0}},  // right
+        {{0, 0, 0}, {1, 0, 0}, {0, 0, 1}}, {{1, 0, 0}, {1, 0, 1}, {0, 0, 1}},  // floor
+        {{0, 1, 0}, {1, 1, 0}, {0, 1, 1}}, {{1, 1, 0}, {1, 1, 1}, {0, 1, 1}},  // top
+        {{0, 0, 0}, {1, 0, 0}, {0, 1, 0}}, {{1, 0, 0}, {1, 1, 0}, {0, 1, 0}},  // front
+        {{1, 1, 1}, {0, 1, 1}, {0, 0, 1}}, {{1, 1, 1}, {0, 0, 1}, {1, 0, 1}},  // back
+    };
+    Composite c;
+    c.kind = Composite::LIST;
+    c.has_box_test = false;
+    for (int k = 0; k < 3; k++) {
+        c.box.mn[k] = p0[k];
+        c.box.mx[k] = p1[k];
+    }
+    int first = -1;
+    for (int f = 0; f < 12; f++) {
+        float pos[9], nrm[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, uv[6] = {0, 0, 0, 0, 0, 0};
+        for (int v = 0; v < 3; v++) {
+            float p[3];
+            for (int k = 0; k < 3; k++) p[k] = sel[f][v][k] ? p1[k] : p0[k];
+            mulPoint(model16, p, 1.0f, &pos[3 * v]);
+        }
+        int id = newTriangle(pos, nrm, uv, mat);
+        if (first < 0) first = id;
+        c.objs.push_back({Obj::TRIANGLE, id});
+    }
+    composites.push_back(std::move(c));
+    world.push_back({Obj::COMPOSITE, (int)composites.size() - 1});
+    return first;
+}
+
+Box3 Scene::objectBox(const Obj& o) const {
+    Box3 b;
+    if (o.kind == Obj::SPHERE) {  // Sphere::BoundingBox, R/src/Core/Hittable.h:257-264
+        const HostSphere& s = spheres[o.id];
+        for (int k = 0; k < 3; k++) {
+            b.mn[k] = s.c[k] - s.r;
+            b.mx[k] = s.c[k] + s.r;
+        }
+        return b;
+    }
+    if (o.kind == Obj::TRIANGLE) return triangleBox(triangles[o.id]);
+    return composites[o.id].box;
+}
+
+// BVHNode::BVHNode, R/src/AccelerationStructures/Bvh.h:18-78.  One randomInt(0,2) per node in
+// pre-order (leaves included); std::sort on the node's own sub-range (a child only ever reads
+// its own sub-range of the parent's sorted copy, so sorting in place is equivalent);
+// mid = start + span/2; max_depth == 0 turns the halves into plain lists.
+int Scene::buildBvh(Composite& c, std::vector<Obj>& objs, size_t start, size_t end, int max_depth) {
+    int axis = randomInt(0, 2);
+    // boxCompare, R/src/AccelerationStructures/Bvh.cpp:3-12
+    auto less = [this, axis](const Obj& a, const Obj& b) { return objectBox(a).mn[axis] < objectBox(b).mn[axis]; };
+    int me = (int)c.nodes.size();
+    c.nodes.emplace_back();
+    size_t span = end - start;
+    Box3 bl, br;
+    if (span == 1) {
+        // left = right = object: Hit() tests it twice with the same outcome; kept once
+        c.nodes[me].leaf = {objs[start]};
+        bl = br = objectBox(objs[start]);
+    } else if (span == 2) {
+        Obj a = objs[start], b = objs[start + 1];
+        if (!less(a, b)) std::swap(a, b);
+        c.nodes[me].leaf = {a, b};
+        bl = objectBox(a);
+        br = objectBox(b);
+    } else {
+        std::sort(objs.begin() + start, objs.begin() + end, less);
+        size_t mid = start + span / 2;
+        if (max_depth == 0) {
+            // two HittableLists; HittableList::BoundingBox folds surroundingBox left to right
+            std::vector<Obj> leaf(objs.begin() + start, objs.begin() + end);
+            bl = objectBox(objs[start]);
+            for (size_t i = start + 1; i < mid; i++) bl = unionBox(bl, objectBox(objs[i]));
+            br = objectBox(objs[mid]);
+            for (size_t i = mid + 1; i < end; i++) br = unionBox(br, objectBox(objs[i]));
+            c.nodes[me].leaf = std::move(leaf);
+        } else {
+            int l = buildBvh(c, objs, start, mid, max_depth - 1);
+            int r = buildBvh(c, objs, mid, end, max_depth - 1);
+            c.nodes[me].left = l;
+            c.nodes[me].right = r;
+            bl = c.nodes[l].box;
+            br = c.nodes[r].box;
+        }
+    }
+    c.nodes[me].box = unionBox(bl, br);
+    return me;
+}
+
+// world = HittableList(make_shared<BVHNode>(world)): Bvh.h:17, unlimited depth.
+void Scene::wrapBvh() {
+    Composite c;
+    c.kind = Composite::BVH;
+    c.has_box_test = true;
+    std::vector<Obj> objs = world;
+    c.root = buildBvh(c, objs, 0, objs.size(), -1);
+    c.box = c.nodes[c.root].box;
+    composites.push_back(std::move(c));
+    world.clear();
+    world.push_back({Obj::COMPOSITE, (int)composites.size() - 1});
+    flat.valid = false;
+}
+
+// Mesh::Mesh + processMesh, R/src/Core/Mesh.cpp:7-37,106-208.
+int Scene::addMesh(const float* model16, int n_vertices, const float* positions, const float* normals, const float* uvs,
+                   int n_triangles, const uint32_t* indices, int mat, int max_depth) {
+    float inv[16];
+    inverse4(model16, inv);
+    Composite mesh;
+    mesh.kind = Composite::MESH;
+    mesh.has_box_test = true;
+    float mn[3] = {kInf, kInf, kInf}, mx[3] = {1e-8f, 1e-8f, 1e-8f};  // Mesh.cpp:16-21
+    std::vector<Obj> tris;
+    tris.reserve(n_triangles);
+    int first = -1;
+    for (int f = 0; f < n_triangles; f++) {
+        float pos[9], nrm[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        float uv[6] = {0.0f, 0.0f, 0.1f, 0.0f, 0.5f, 1.0f};  // Mesh.cpp:122-124 defaults
+        for (int k = 0; k < 3; k++) {
+            uint32_t vi = indices[3 * f + k];
+            if ((int)vi >= n_vertices) return -1;
+            mulPoint(model16, &positions[3 * vi], 1.0f, &pos[3 * k]);  // Mesh.cpp:145-147
+            if (uvs) {
+                uv[2 * k] = uvs[2 * vi];
+                uv[2 * k + 1] = uvs[2 * vi + 1];
+            }
+            if (normals) {
+                float n[3];
+                normalize3(&normals[3 * vi], n);  // Mesh.cpp:139-141
+                // mat3(transpose(inverse(M))) * n: column j of that matrix is row j of inv (Mesh.cpp:144,148-150)
+                for (int r = 0; r < 3; r++)
+                    nrm[3 * k + r] = (inv[r * 4 + 0] * n[0] + inv[r * 4 + 1] * n[1]) + inv[r * 4 + 2] * n[2];
+            }
+        }
+        int id = newTriangle(pos, nrm, uv, mat);
+        if (first < 0) first = id;
+        tris.push_back({Obj::TRIANGLE, id});
+        for (int a = 0; a < 3; a++) {  // Mesh.cpp:165-207
+            for (int k = 0; k < 3; k++)
+                if (pos[3 * k + a] < mn[a]) mn[a] = pos[3 * k + a];
+            for (int k = 0; k < 3; k++)
+                if (pos[3 * k + a] > mx[a]) mx[a] = pos[3 * k + a];
+        }
+    }
+    for (int a = 0; a < 3; a++) {
+        mesh.box.mn[a] = mn[a];
+        mesh.box.mx[a] = mx[a];
+    }
+    // BVHNode(triangles, 0, n, maxDepth); triangles = { bvh }  (Mesh.cpp:29-31)
+    Composite bvh;
+    bvh.kind = Composite::BVH;
+    bvh.has_box_test = true;
+    bvh.root = buildBvh(bvh, tris, 0, tris.size(), max_depth);
+    bvh.box = bvh.nodes[bvh.root].box;
+    composites.push_back(std::move(bvh));
+    mesh.objs.push_back({Obj::COMPOSITE, (int)composites.size() - 1});
+    composites.push_back(std::move(mesh));
+    world.push_back({Obj::COMPOSITE, (int)composites.size() - 1});
+    flat.valid = false;
+    return first;
+}
+
+// The subset of glTF 2.0 that the reference's one model needs: a single mesh primitive with
+// float POSITION / NORMAL / TEXCOORD_0 accessors and u16 or u32 indices in an external .bin.
+// The V texture coordinate is flipped (1 - v), which is what the importer used by the
+// reference hands to R/src/Core/Mesh.cpp:125-133 for glTF files.
+int Scene::addMeshGltf(const float* model16, const char* path, int mat, int max_depth, std::string* err) {
+    std::string text;
+    if (!readFile(path, &text)) {
+        *err = std::string("cannot read ") + path;
+        return -1;
+    }
+    JParser jp(text);
+    JValue root = jp.parse();
+    if (!jp.ok || root.t != JValue::OBJ) {
+        *err = "malformed glTF JSON";
+        return -1;
+    }
+    const JValue *meshes = root.get("meshes"), *accessors = root.get("accessors"), *views = root.get("bufferViews"),
+                 *buffers = root.get("buffers");
+    if (!meshes || !accessors || !views || !buffers || meshes->arr.empty()) {
+        *err = "glTF lacks meshes/accessors/bufferViews/buffers";
+        return -1;
+    }
+    std::string dir(path);
+    size_t slash = dir.find_last_of('/');
+    dir = slash == std::string::npos ? std::string(".") : dir.substr(0, slash);
+    std::vector<std::string> blobs(buffers->arr.size());
+    for (size_t i = 0; i < buffers->arr.size(); i++) {
+        const JValue* uri = buffers->arr[i].get("uri");
+        if (!uri || !readFile(dir + "/" + uri->str, &blobs[i])) {
+            *err = "cannot read glTF buffer";
+            return -1;
+        }
+    }
+    const JValue* prims = meshes->arr[0].get("primitives");
+    if (!prims || prims->arr.empty()) {
+        *err = "mesh without primitives";
+        return -1;
+    }
+    const JValue& prim = prims->arr[0];
+    const JValue* attrs = prim.get("attributes");
+    const JValue* idxAcc = prim.get("indices");
+    if (!attrs || !attrs->get("POSITION") || !idxAcc) {
+        *err = "primitive needs POSITION and indices";
+        return -1;
+    }
+    struct View {
+        const char* data;
+        size_t count;
+        int comp;
+        size_t stride;
+    };
+    auto view = [&](int acc, int ncomp, size_t compSize, View* out) -> bool {
+        if (acc < 0 || acc >= (int)accessors->arr.size()) return false;
+        const JValue& a = accessors->arr[acc];
+        const JValue *bv = a.get("bufferView"), *cnt = a.get("count"), *ct = a.get("componentType");
+        if (!bv || !cnt || !ct) return false;
+        const JValue& v = views->arr[(int)bv->num];
+        const JValue *buf = v.get("buffer"), *off = v.get("byteOffset"), *st = v.get("byteStride");
+        size_t offset = (off ? (size_t)off->num : 0) + (a.get("byteOffset") ? (size_t)a.get("byteOffset")->num : 0);
+        const std::string& blob = blobs[buf ? (int)buf->num : 0];
+        out->count = (size_t)cnt->num;
+        out->comp = (int)ct->num;
+        out->stride = st ? (size_t)st->num : ncomp * compSize;
+        if (offset + (out->count ? (out->count - 1) * out->stride + ncomp * compSize : 0) > blob.size()) return false;
+        out->data = blob.data() + offset;
+        return true;
+    };
+    View vp{}, vn{}, vt{}, vi{};
+    if (!view((int)attrs->get("POSITION")->num, 3, 4, &vp) || vp.comp != 5126) {
+        *err = "bad POSITION accessor";
+        return -1;
+    }
+    bool hasN = attrs->get("NORMAL") && view((int)attrs->get("NORMAL")->num, 3, 4, &vn) && vn.comp == 5126;
+    bool hasT = attrs->get("TEXCOORD_0") && view((int)attrs->get("TEXCOORD_0")->num, 2, 4, &vt) && vt.comp == 5126;
+    int idxComp = (int)accessors->arr[(int)idxAcc->num].get("componentType")->num;
+    size_t idxSize = idxComp == 5123 ? 2 : (idxComp == 5125 ? 4 : 0);
+    if (!idxSize || !view((int)idxAcc->num, 1, idxSize, &vi)) {
+        *err = "bad index accessor";
+        return -1;
+    }
+    size_t nv = vp.count;
+    std::vector<float> P(nv * 3), N, T;
+    for (size_t i = 0; i < nv; i++) std::memcpy(&P[3 * i], vp.data + i * vp.stride, 12);
+    if (hasN && vn.count == nv) {
+        N.resize(nv * 3);
+        for (size_t i = 0; i < nv; i++) std::memcpy(&N[3 * i], vn.data + i * vn.stride, 12);
+    }
+    if (hasT && vt.count == nv) {
+        T.resize(nv * 2);
+        for (size_t i = 0; i < nv; i++) {
+            float uvv[2];
+            std::memcpy(uvv, vt.data + i * vt.stride, 8);
+            T[2 * i] = uvv[0];
+            T[2 * i + 1] = 1.0f - uvv[1];
+        }
+    }
+    std::vector<uint32_t> I(vi.count);
+    for (size_t i = 0; i < vi.count; i++) {
+        if (idxSize == 2) {
+            uint16_t v;
+            std::memcpy(&v, vi.data + i * vi.stride, 2);
+            I[i] = v;
+        } else {
+            std::memcpy(&I[i], vi.data + i * vi.stride, 4);
+        }
+    }
+    int r = addMesh(model16, (int)nv, P.data(), N.empty() ? nullptr : N.data(), T.empty() ? nullptr : T.data(),
+                    (int)(I.size() / 3), I.data(), mat, max_depth);
+    if (r < 0) *err = "index out of range in glTF mesh";
+    return r;
+}
+
+// randomScene(), R/src/RaytracingApplication.cpp:359-405.  The distance test at :370 calls
+// vec3::length(), glm's component count (3), so it never rejects: 22*22 + 4 = 488 spheres.
+// Draw order inside one constructor argument list is the g++ order (right to left).
+void Scene::randomScene() {
+    addSphere(0.0f, -1000.0f, 0.0f, 1000.0f, addMaterial(0, 0.5f, 0.5f, 0.5f, 0));
+    for (int a = -11; a < 11; a++) {
+        for (int b = -11; b < 11; b++) {
+            float chooseMat = randomFloat();
+            float drawZ = randomFloat();  // third constructor argument is evaluated first
+            float drawX = randomFloat();
+            float cx = a + 0.9f * drawX, cy = 0.2f, cz = b + 0.9f * drawZ;
+            int m;
+            if (chooseMat < 0.8f) {
+                float p[3], q[3];
+                randomVec(p);
+                randomVec(q);
+                m = addMaterial(0, q[0] * p[0], q[1] * p[1], q[2] * p[2], 0);
+            } else if (chooseMat < 0.95f) {
+                float alb[3];
+                randomVec(0.5f, 1.0f, alb);
+                float fuzz = randomFloat(0.0f, 0.5f);
+                m = addMaterial(1, alb[0], alb[1], alb[2], fuzz);
+            } else {
+                m = addMaterial(2, 0, 0, 0, 1.5f);
+            }
+            addSphere(cx, cy, cz, 0.2f, m);
+        }
+    }
+    addSphere(0.0f, 1.0f, 0.0f, 1.0f, addMaterial(2, 0, 0, 0, 1.5f));
+    addSphere(-4.0f, 1.0f, 0.0f, 1.0f, addMaterial(0, 0.4f, 0.2f, 0.1f, 0));
+    addSphere(4.0f, 1.0f, 0.0f, 1.0f, addMaterial(1, 0.7f, 0.6f, 0.5f, 0.0f));
+}
+
+// cornellBox(), R/src/RaytracingApplication.cpp:407-478: twelve flat-shaded triangles.
+void Scene::cornellBox() {
+    int red = addMaterial(0, 0.65f, 0.05f, 0.05f, 0);
+    int white = addMaterial(0, 0.73f, 0.73f, 0.73f, 0);
+    int green = addMaterial(0, 0.12f, 0.45f, 0.15f, 0);
+    int light = addMaterial(3, 15.0f, 15.0f, 15.0f, 0);
+    struct T {
+        float p[9];
+        int m;
+    };
+    const T tris[12] = {
+        {{555, 0, 0, 555, 555, 0, 555, 555, 555}, green},   {{555, 0, 0, 555, 555, 555, 555, 0, 555}, green},
+        {{0, 0, 0, 0, 555, 0, 0, 555, 555}, red},           {{0, 0, 0, 0, 555, 555, 0, 0, 555}, red},
+        {{213, 554, 227, 343, 554, 227, 343, 554, 332}, light}, {{213, 554, 227, 343, 554, 332, 213, 554, 332}, light},
+        {{0, 0, 0, 555, 0, 0, 555, 0, 555}, white},         {{0, 0, 0, 555, 0, 555, 0, 0, 555}, white},
+        {{0, 555, 0, 555, 555, 0, 555, 555, 555}, white},   {{0, 555, 0, 555, 555, 555, 0, 555, 555}, white},
+        {{0, 0, 555, 555, 0, 555, 555, 555, 555}, white},   {{0, 0, 555, 555, 555, 555, 0, 555, 555}, white},
+    };
+    const float zero9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, zero6[6] = {0, 0, 0, 0, 0, 0};
+    for (const T& t : tris) addTriangle(t.p, zero9, zero6, t.m);
+}
+
+// Camera::Camera, R/src/Core/Camera.h:7-25.
+void Scene::setCamera(const float* lookfrom, const float* lookat, const float* vup, float vfov, float aspect,
+                      float aperture, float focus) {
+    float theta = vfov * 0.01745329251994329576923690768489f;  // glm::radians
+    float h = std::tan(theta / 2.0f);
+    float viewportHeight = 2.0f * h;
+    float viewportWidth = aspect * viewportHeight;
+    float d[3] = {lookfrom[0] - lookat[0], lookfrom[1] - lookat[1], lookfrom[2] - lookat[2]};
+    float w[3], u[3], v[3], c[3];
+    normalize3(d, w);
+    cross3(vup, w, c);
+    normalize3(c, u);
+    cross3(w, u, v);
+    float fw = focus * viewportWidth, fh = focus * viewportHeight;
+    for (int k = 0; k < 3; k++) {
+        camera.origin[k] = lookfrom[k];
+        camera.horizontal[k] = fw * u[k];
+        camera.vertical[k] = fh * v[k];
+        camera.u[k] = u[k];
+        camera.v[k] = v[k];
+        camera.w[k] = w[k];
+        camera.llc[k] = ((camera.origin[k] - camera.horizontal[k] / 2.0f) - camera.vertical[k] / 2.0f) - focus * w[k];
+    }
+    camera.lens_radius = aperture / 2;
+}
+
+// ---------------------------------------------------------------------------- flatten
+int Scene::newEntry(const Box3* box) {
+    int idx = (int)(flat.nodes.size() / 8);
+    uint32_t w[8];
+    for (int k = 0; k < 3; k++) {
+        w[k] = box ? bitsOf(box->mn[k]) : 0u;
+        w[4 + k] = box ? bitsOf(box->mx[k]) : 0u;
+    }
+    w[3] = (uint32_t)(idx + 1) | (box ? 0u : kNodeNoBox);
+    w[7] = 0xFFFFFFFFu;  // first_ref = -1
+    flat.nodes.insert(flat.nodes.end(), w, w + 8);
+    return idx;
+}
+
+// Emits a HittableList's objects in order.  A run of consecutive primitives becomes one
+// leaf run; the first run directly under a box-tested entry rides on that entry.
+void Scene::emitObjects(const std::vector<Obj>& objs, int parent_entry) {
+    bool can_attach = parent_entry >= 0;
+    size_t i = 0;
+    while (i < objs.size()) {
+        if (objs[i].kind != Obj::COMPOSITE) {
+            size_t j = i;
+            uint32_t first = (uint32_t)flat.prim_refs.size();
+            while (j < objs.size() && objs[j].kind != Obj::COMPOSITE) {
+                flat.prim_refs.push_back((uint32_t)objs[j].id | (objs[j].kind == Obj::TRIANGLE ? kRefTriangle : 0u));
+                j++;
+            }
+            flat.prim_refs.back() |= kRefLast;
+            flat.max_leaf = std::max(flat.max_leaf, (int)(j - i));
+            int e = can_attach ? parent_entry : newEntry(nullptr);
+            flat.nodes[(size_t)e * 8 + 7] = first;
+            i = j;
+        } else {
+            emitComposite(composites[objs[i].id]);
+            i++;
+        }
+        can_attach = false;
+    }
+}
+
+void Scene::emitBvhNode(const Composite& c, int node) {
+    const BvhNode& n = c.nodes[node];
+    int e = newEntry(&n.box);
+    if (n.left >= 0) {
+        emitBvhNode(c, n.left);
+        emitBvhNode(c, n.right);
+    } else {
+        emitObjects(n.leaf, e);
+    }
+    uint32_t end = (uint32_t)(flat.nodes.size() / 8);
+    flat.nodes[(size_t)e * 8 + 3] = end;  // a miss jumps past the whole subtree
+}
+
+void Scene::emitComposite(const Composite& c) {
+    if (c.kind == Composite::BVH) {
+        emitBvhNode(c, c.root);
+    } else if (c.kind == Composite::MESH) {
+        int e = newEntry(&c.box);
+        emitObjects(c.objs, e);
+        flat.nodes[(size_t)e * 8 + 3] = (uint32_t)(flat.nodes.size() / 8);
+    } else {
+        emitObjects(c.objs, -1);
+    }
+}
+
+void Scene::flatten() {
+    if (flat.valid) return;
+    flat.nodes.clear();
+    flat.prim_refs.clear();
+    flat.max_leaf = 0;
+    emitObjects(world, -1);
+    flat.valid = true;
+}
+
+}  // namespace rt

@@ -1,0 +1,121 @@
+// Host-side scene construction and the BVH flatten step (no device code here).
+// R/ = /root/reference/Raytracing-In-A-Weekend/ in the citations below.
+#pragma once
+#include <cstdint>
+#include <random>
+#include <string>
+#include <vector>
+
+namespace rt {
+
+struct Box3 {
+    float mn[3], mx[3];
+};
+
+// One entry of HittableList::objects (R/src/Core/Hittable.h:315): a primitive or a composite.
+struct Obj {
+    enum Kind : int { SPHERE = 0, TRIANGLE = 1, COMPOSITE = 2 } kind;
+    int id;  // sphere id, triangle id, or index into Scene::composites
+};
+
+// A node of a built BVH (R/src/AccelerationStructures/Bvh.h:13-100).
+struct BvhNode {
+    Box3 box;
+    int left = -1, right = -1;  // child node indices when both children are BVH nodes
+    std::vector<Obj> leaf;      // otherwise: the objects under this node, in the order Hit() visits them
+};
+
+struct Composite {
+    enum Kind : int { BVH = 0, MESH = 1, LIST = 2 } kind;
+    Box3 box;                // BVH root box, Mesh::boundingBox, or an explicit list box (Box class)
+    bool has_box_test;       // BVH and MESH test `box` before descending; a plain list does not
+    std::vector<Obj> objs;   // MESH / LIST children in order
+    std::vector<BvhNode> nodes;  // BVH only
+    int root = -1;
+};
+
+struct HostMaterial {
+    int kind;
+    float r, g, b, param;
+    int tex_d, tex_r, tex_n;
+};
+struct HostTexture {
+    int w, h;
+    std::vector<uint8_t> rgb;
+};
+struct HostSphere {
+    float c[3], r;
+    int mat;
+};
+struct HostTriangle {
+    float pos[9], nrm[9], uv[6];
+    int mat;
+};
+
+struct FlatScene {
+    // 8 words per entry: {min.xyz, skip|flags, max.xyz, first_ref}
+    std::vector<uint32_t> nodes;
+    std::vector<uint32_t> prim_refs;
+    int max_leaf = 0;
+    bool valid = false;
+};
+
+constexpr uint32_t kNodeNoBox = 1u << 30;     // entry without a box test
+constexpr uint32_t kNodeSkipMask = kNodeNoBox - 1;
+constexpr uint32_t kRefLast = 1u << 31;       // last reference of its leaf run
+constexpr uint32_t kRefTriangle = 1u << 30;
+constexpr uint32_t kRefIdMask = kRefTriangle - 1;
+
+struct Camera22 {
+    float origin[3], llc[3], horizontal[3], vertical[3], u[3], v[3], w[3], lens_radius;
+};
+
+class Scene {
+public:
+    Scene();
+    // --- RNG (R/src/Core/RTWeekend.h:26-58) ---
+    float randomFloat();
+    float randomFloat(float mn, float mx) { return mn + (mx - mn) * randomFloat(); }
+    int randomInt(int mn, int mx) { return static_cast<int>(randomFloat((float)mn, (float)(mx + 1))); }
+    void randomVec(float out[3]);
+    void randomVec(float mn, float mx, float out[3]);
+
+    int addMaterial(int kind, float r, float g, float b, float param);
+    int addTexture(int w, int h, const uint8_t* rgb);
+    int addPbr(int td, int tr, int tn);
+    int addSphere(float cx, float cy, float cz, float r, int mat);
+    int addTriangle(const float* pos9, const float* nrm9, const float* uv6, int mat);
+    int addBox(const float* p0, const float* p1, int mat, const float* model16);
+    int addMesh(const float* model16, int n_vertices, const float* positions, const float* normals, const float* uvs,
+                int n_triangles, const uint32_t* indices, int mat, int max_depth);
+    int addMeshGltf(const float* model16, const char* path, int mat, int max_depth, std::string* err);
+    void randomScene();
+    void cornellBox();
+    void wrapBvh();
+    void setCamera(const float* lookfrom, const float* lookat, const float* vup, float vfov, float aspect, float aperture,
+                   float focus);
+    void flatten();
+
+    Box3 objectBox(const Obj& o) const;
+
+    std::vector<HostMaterial> materials;
+    std::vector<HostTexture> textures;
+    std::vector<HostSphere> spheres;
+    std::vector<HostTriangle> triangles;
+    std::vector<Composite> composites;
+    std::vector<Obj> world;  // Scene::world.objects
+    Camera22 camera{};
+    float background[3] = {0, 0, 0};
+    FlatScene flat;
+
+private:
+    int newTriangle(const float* pos9, const float* nrm9, const float* uv6, int mat);
+    int buildBvh(Composite& c, std::vector<Obj>& objs, size_t start, size_t end, int max_depth);
+    void emitObjects(const std::vector<Obj>& objs, int parent_entry);
+    void emitComposite(const Composite& c);
+    void emitBvhNode(const Composite& c, int node);
+    int newEntry(const Box3* box);
+    std::mt19937 gen_;
+};
+
+}  // namespace rt

@@ -1,0 +1,693 @@
+// C ABI of the path tracer core (declarations and reference citations: include/rtiow_hip.h).
+// There is no CPU fallback: every device entry point fails with RT_ERR_NO_DEVICE / RT_ERR_HIP
+// when the HIP runtime cannot run the kernels.
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rtiow_hip.h"
+#include "host_scene.h"
+#include "rt_device.h"
+
+namespace rt {
+hipError_t launchRender(const RenderArgs& a, bool lds, bool count, int blocks, int threads, hipStream_t stream);
+hipError_t launchTrace(const DevScene& sc, int n, const float* rays, int* kind, int* id, float* t, float* normal,
+                       int* front, float* uv, hipStream_t stream);
+hipError_t launchScatter(const DevScene& sc, int n, const int* mat, const float* rayIn, const float* p, const float* nrm,
+                         const int* front, const float* uv, const unsigned int* key4, float* atten, float* rayOut,
+                         int* alive, unsigned int* counterOut, hipStream_t stream);
+hipError_t launchResolve(const float4* payloads, size_t stride4, int width, int height, int tiles_per_row_local,
+                         int world, int only_rank, int mode, int spp, float4* out32, uint32_t* out8, hipStream_t stream);
+}  // namespace rt
+
+struct rt_scene {
+    rt::Scene sc;
+};
+
+struct rt_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    rt::DevScene dsc{};
+    std::vector<void*> scene_allocs;
+    bool scene_loaded = false;
+    size_t lds_need = 0;
+    bool use_lds = false;
+    int n_cus = 256;
+    int width = 0, height = 0, rank = 0, world = 1;
+    int tiles_x = 0, tiles_y = 0, tprl = 0, n_local_tiles = 0;
+    float4* accum = nullptr;
+    bool accum_owned = false;
+    unsigned int* queue = nullptr;
+    unsigned long long* counters = nullptr;
+    std::atomic<int> cancel{0};
+};
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) return fail(RT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+// Largest LDS footprint the staged-scene kernel is allowed to ask for.  Two such workgroups
+// still fit the 160 KiB of a CU.
+constexpr size_t kMaxLdsScene = 64 * 1024;
+
+int envInt(const char* name, int dflt) {
+    const char* v = std::getenv(name);
+    return v ? std::atoi(v) : dflt;
+}
+
+template <class T>
+int devUpload(rt_context* ctx, const std::vector<T>& host, const T** out) {
+    size_t bytes = std::max<size_t>(host.size() * sizeof(T), 16);
+    void* d = nullptr;
+    HIP_TRY(hipMalloc(&d, bytes));
+    ctx->scene_allocs.push_back(d);
+    if (!host.empty()) HIP_TRY(hipMemcpyAsync(d, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    *out = reinterpret_cast<const T*>(d);
+    return RT_OK;
+}
+
+void freeScene(rt_context* ctx) {
+    for (void* p : ctx->scene_allocs) (void)hipFree(p);
+    ctx->scene_allocs.clear();
+    ctx->scene_loaded = false;
+}
+
+void freeTarget(rt_context* ctx) {
+    if (ctx->accum && ctx->accum_owned) (void)hipFree(ctx->accum);
+    ctx->accum = nullptr;
+    ctx->accum_owned = false;
+}
+
+void tileGeometry(int width, int height, int world, int* tiles_x, int* tiles_y, int* tprl) {
+    *tiles_x = (width + rt::kTile - 1) / rt::kTile;
+    *tiles_y = (height + rt::kTile - 1) / rt::kTile;
+    *tprl = (*tiles_x + world - 1) / world;
+}
+
+rt::RenderArgs makeArgs(rt_context* ctx, int first_sample, int n_samples, int max_depth) {
+    rt::RenderArgs a{};
+    a.sc = ctx->dsc;
+    a.accum = ctx->accum;
+    a.queue = nullptr;
+    a.counters = ctx->counters;
+    a.width = ctx->width;
+    a.height = ctx->height;
+    a.tiles_x = ctx->tiles_x;
+    a.tiles_y = ctx->tiles_y;
+    a.tiles_per_row_local = ctx->tprl;
+    a.n_local_tiles = ctx->n_local_tiles;
+    a.rank = ctx->rank;
+    a.world = ctx->world;
+    a.first_sample = first_sample;
+    a.n_samples = n_samples;
+    a.max_depth = max_depth;
+    a.lds_bytes = (int)ctx->lds_need;
+    return a;
+}
+
+int checkRenderState(rt_context* ctx) {
+    if (!ctx) return fail(RT_ERR_INVALID, "null context");
+    if (!ctx->scene_loaded) return fail(RT_ERR_STATE, "rt_upload_scene() has not been called");
+    if (!ctx->accum) return fail(RT_ERR_STATE, "rt_set_target() has not been called");
+    return RT_OK;
+}
+
+int launch(rt_context* ctx, rt::RenderArgs& a, bool count) {
+    const int threads = 256;
+    const int wavesPerBlock = threads / 64;
+    int blocks;
+    const bool persistent = envInt("RT_PERSISTENT", 0) != 0;
+    if (persistent) {
+        HIP_TRY(hipMemsetAsync(ctx->queue, 0, sizeof(unsigned int), ctx->stream));
+        a.queue = ctx->queue;
+        blocks = ctx->n_cus * envInt("RT_BLOCKS_PER_CU", 2);
+    } else {
+        blocks = (a.n_local_tiles + wavesPerBlock - 1) / wavesPerBlock;
+    }
+    if (blocks < 1) blocks = 1;
+    HIP_TRY(rt::launchRender(a, ctx->use_lds, count, blocks, threads, ctx->stream));
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rt_last_error(void) { return g_err.c_str(); }
+const char* rt_version(void) { return "rtiow-hip 0.1 (gfx950)"; }
+
+// ------------------------------------------------------------------ scene (host)
+int rt_scene_create(rt_scene** out) {
+    if (!out) return fail(RT_ERR_INVALID, "null output pointer");
+    *out = new rt_scene();
+    return RT_OK;
+}
+void rt_scene_destroy(rt_scene* s) { delete s; }
+
+int rt_scene_rng_floats(rt_scene* s, int n, float* out) {
+    if (!s || n < 0 || (n && !out)) return fail(RT_ERR_INVALID, "bad arguments");
+    for (int i = 0; i < n; i++) out[i] = s->sc.randomFloat();
+    return RT_OK;
+}
+int rt_scene_add_material(rt_scene* s, int kind, float r, float g, float b, float param) {
+    if (!s || kind < RT_MAT_LAMBERTIAN || kind > RT_MAT_LIGHT) return fail(RT_ERR_INVALID, "bad material kind");
+    return s->sc.addMaterial(kind, r, g, b, param);
+}
+int rt_scene_add_texture_rgb8(rt_scene* s, int width, int height, const uint8_t* rgb) {
+    if (!s || width <= 0 || height <= 0 || !rgb) return fail(RT_ERR_INVALID, "bad texture");
+    return s->sc.addTexture(width, height, rgb);
+}
+int rt_scene_add_material_pbr(rt_scene* s, int td, int tr, int tn) {
+    if (!s) return fail(RT_ERR_INVALID, "null scene");
+    const int nt = (int)s->sc.textures.size();
+    if (td < 0 || td >= nt || tr >= nt || tn >= nt) return fail(RT_ERR_INVALID, "texture index out of range");
+    return s->sc.addPbr(td, tr < 0 ? -1 : tr, tn < 0 ? -1 : tn);
+}
+static bool matOk(rt_scene* s, int m) { return s && m >= 0 && m < (int)s->sc.materials.size(); }
+int rt_scene_add_sphere(rt_scene* s, float cx, float cy, float cz, float radius, int material) {
+    if (!matOk(s, material)) return fail(RT_ERR_INVALID, "material index out of range");
+    return s->sc.addSphere(cx, cy, cz, radius, material);
+}
+int rt_scene_add_triangle(rt_scene* s, const float* pos9, const float* normal9, const float* uv6, int material) {
+    if (!matOk(s, material) || !pos9 || !normal9 || !uv6) return fail(RT_ERR_INVALID, "bad triangle arguments");
+    return s->sc.addTriangle(pos9, normal9, uv6, material);
+}
+int rt_scene_add_box(rt_scene* s, const float* p0, const float* p1, int material, const float* model16) {
+    if (!matOk(s, material) || !p0 || !p1 || !model16) return fail(RT_ERR_INVALID, "bad box arguments");
+    return s->sc.addBox(p0, p1, material, model16);
+}
+int rt_scene_add_mesh(rt_scene* s, const float* model16, int n_vertices, const float* positions, const float* normals,
+                      const float* uvs, int n_triangles, const uint32_t* indices, int material, int max_depth) {
+    if (!matOk(s, material) || !model16 || !positions || !indices || n_vertices <= 0 || n_triangles <= 0)
+        return fail(RT_ERR_INVALID, "bad mesh arguments");
+    int r = s->sc.addMesh(model16, n_vertices, positions, normals, uvs, n_triangles, indices, material, max_depth);
+    if (r < 0) return fail(RT_ERR_INVALID, "mesh index out of range");
+    return r;
+}
+int rt_scene_add_mesh_gltf(rt_scene* s, const float* model16, const char* gltf_path, int material, int max_depth) {
+    if (!matOk(s, material) || !model16 || !gltf_path) return fail(RT_ERR_INVALID, "bad mesh arguments");
+    std::string err;
+    int r = s->sc.addMeshGltf(model16, gltf_path, material, max_depth, &err);
+    if (r < 0) return fail(RT_ERR_INVALID, err);
+    return r;
+}
+int rt_scene_random_scene(rt_scene* s) {
+    if (!s) return fail(RT_ERR_INVALID, "null scene");
+    s->sc.randomScene();
+    return RT_OK;
+}
+int rt_scene_cornell_box(rt_scene* s) {
+    if (!s) return fail(RT_ERR_INVALID, "null scene");
+    s->sc.cornellBox();
+    return RT_OK;
+}
+int rt_scene_wrap_bvh(rt_scene* s) {
+    if (!s) return fail(RT_ERR_INVALID, "null scene");
+    if (s->sc.world.empty()) return fail(RT_ERR_STATE, "cannot build a BVH over an empty world");
+    s->sc.wrapBvh();
+    return RT_OK;
+}
+int rt_scene_set_camera(rt_scene* s, const float* lookfrom3, const float* lookat3, const float* vup3, float vfov,
+                        float aspect_ratio, float aperture, float focus_dist) {
+    if (!s || !lookfrom3 || !lookat3 || !vup3) return fail(RT_ERR_INVALID, "bad camera arguments");
+    s->sc.setCamera(lookfrom3, lookat3, vup3, vfov, aspect_ratio, aperture, focus_dist);
+    return RT_OK;
+}
+int rt_scene_get_camera(const rt_scene* s, float* out22) {
+    if (!s || !out22) return fail(RT_ERR_INVALID, "bad arguments");
+    std::memcpy(out22, &s->sc.camera, sizeof(float) * 22);
+    return RT_OK;
+}
+int rt_scene_set_background(rt_scene* s, float r, float g, float b) {
+    if (!s) return fail(RT_ERR_INVALID, "null scene");
+    s->sc.background[0] = r;
+    s->sc.background[1] = g;
+    s->sc.background[2] = b;
+    return RT_OK;
+}
+
+int rt_scene_flatten(rt_scene* s, rt_flat_info* info) {
+    if (!s) return fail(RT_ERR_INVALID, "null scene");
+    s->sc.flatten();
+    if (info) {
+        const rt::Scene& sc = s->sc;
+        info->n_nodes = (int)(sc.flat.nodes.size() / 8);
+        info->n_prim_refs = (int)sc.flat.prim_refs.size();
+        info->n_spheres = (int)sc.spheres.size();
+        info->n_triangles = (int)sc.triangles.size();
+        info->n_materials = (int)sc.materials.size();
+        info->n_textures = (int)sc.textures.size();
+        info->max_leaf = sc.flat.max_leaf;
+        info->fits_lds =
+            rt::ldsSceneBytes(info->n_nodes, info->n_prim_refs, info->n_spheres, info->n_triangles) <= kMaxLdsScene;
+    }
+    return RT_OK;
+}
+
+int rt_scene_get_flat(const rt_scene* s, uint32_t* nodes8, uint32_t* prim_refs, float* spheres4, int32_t* sphere_mat,
+                      float* tri_pos9, float* tri_normal9, float* tri_uv6, int32_t* tri_mat, int32_t* mat_kind,
+                      float* mat_rgbp4) {
+    if (!s) return fail(RT_ERR_INVALID, "null scene");
+    const rt::Scene& sc = s->sc;
+    if (!sc.flat.valid) return fail(RT_ERR_STATE, "rt_scene_flatten() has not been called");
+    if (nodes8) std::memcpy(nodes8, sc.flat.nodes.data(), sc.flat.nodes.size() * 4);
+    if (prim_refs) std::memcpy(prim_refs, sc.flat.prim_refs.data(), sc.flat.prim_refs.size() * 4);
+    for (size_t i = 0; i < sc.spheres.size(); i++) {
+        if (spheres4) {
+            std::memcpy(&spheres4[4 * i], sc.spheres[i].c, 12);
+            spheres4[4 * i + 3] = sc.spheres[i].r;
+        }
+        if (sphere_mat) sphere_mat[i] = sc.spheres[i].mat;
+    }
+    for (size_t i = 0; i < sc.triangles.size(); i++) {
+        if (tri_pos9) std::memcpy(&tri_pos9[9 * i], sc.triangles[i].pos, 36);
+        if (tri_normal9) std::memcpy(&tri_normal9[9 * i], sc.triangles[i].nrm, 36);
+        if (tri_uv6) std::memcpy(&tri_uv6[6 * i], sc.triangles[i].uv, 24);
+        if (tri_mat) tri_mat[i] = sc.triangles[i].mat;
+    }
+    for (size_t i = 0; i < sc.materials.size(); i++) {
+        if (mat_kind) mat_kind[i] = sc.materials[i].kind;
+        if (mat_rgbp4) {
+            mat_rgbp4[4 * i] = sc.materials[i].r;
+            mat_rgbp4[4 * i + 1] = sc.materials[i].g;
+            mat_rgbp4[4 * i + 2] = sc.materials[i].b;
+            mat_rgbp4[4 * i + 3] = sc.materials[i].param;
+        }
+    }
+    return RT_OK;
+}
+
+// ------------------------------------------------------------------ device
+int rt_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int rt_create(int device, rt_context** out) {
+    if (!out) return fail(RT_ERR_INVALID, "null output pointer");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(RT_ERR_NO_DEVICE, "no HIP device available; this library has no CPU path");
+    if (device < 0 || device >= n) return fail(RT_ERR_INVALID, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    rt_context* ctx = new rt_context();
+    ctx->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->n_cus = prop.multiProcessorCount;
+    hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
+    if (e == hipSuccess) e = hipMalloc((void**)&ctx->queue, 256);
+    if (e == hipSuccess) e = hipMalloc((void**)&ctx->counters, 256);
+    if (e != hipSuccess) {
+        rt_destroy(ctx);
+        return fail(RT_ERR_HIP, std::string("context set-up: ") + hipGetErrorString(e));
+    }
+    *out = ctx;
+    return RT_OK;
+}
+
+void rt_destroy(rt_context* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    freeScene(ctx);
+    freeTarget(ctx);
+    if (ctx->queue) (void)hipFree(ctx->queue);
+    if (ctx->counters) (void)hipFree(ctx->counters);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int rt_upload_scene(rt_context* ctx, rt_scene* s) {
+    if (!ctx || !s) return fail(RT_ERR_INVALID, "null handle");
+    HIP_TRY(hipSetDevice(ctx->device));
+    rt::Scene& sc = s->sc;
+    sc.flatten();
+    if (sc.flat.nodes.empty()) return fail(RT_ERR_STATE, "the world is empty");
+    for (const auto& m : sc.materials)
+        if (m.kind == RT_MAT_PBR && (m.tex_d < 0 || m.tex_d >= (int)sc.textures.size()))
+            return fail(RT_ERR_INVALID, "PBR material without a diffuse texture");
+    freeScene(ctx);
+
+    const int nNodes = (int)(sc.flat.nodes.size() / 8);
+    if ((uint32_t)nNodes >= rt::kNodeSkipMask) return fail(RT_ERR_LIMIT, "too many BVH entries");
+    std::vector<float4> spheres(sc.spheres.size());
+    std::vector<int> sphereMat(sc.spheres.size());
+    for (size_t i = 0; i < sc.spheres.size(); i++) {
+        spheres[i] = make_float4(sc.spheres[i].c[0], sc.spheres[i].c[1], sc.spheres[i].c[2], sc.spheres[i].r);
+        sphereMat[i] = sc.spheres[i].mat;
+    }
+    std::vector<float4> triI(sc.triangles.size() * 3), triS(sc.triangles.size() * 4);
+    std::vector<int> triMat(sc.triangles.size());
+    for (size_t i = 0; i < sc.triangles.size(); i++) {
+        const rt::HostTriangle& t = sc.triangles[i];
+        // edge1 = v1 - v0, edge2 = v2 - v0 (R/src/Core/Hittable.h:64-65), computed once here
+        triI[3 * i] = make_float4(t.pos[0], t.pos[1], t.pos[2], 0.f);
+        triI[3 * i + 1] = make_float4(t.pos[3] - t.pos[0], t.pos[4] - t.pos[1], t.pos[5] - t.pos[2], 0.f);
+        triI[3 * i + 2] = make_float4(t.pos[6] - t.pos[0], t.pos[7] - t.pos[1], t.pos[8] - t.pos[2], 0.f);
+        triS[4 * i] = make_float4(t.nrm[0], t.nrm[1], t.nrm[2], t.uv[0]);
+        triS[4 * i + 1] = make_float4(t.nrm[3], t.nrm[4], t.nrm[5], t.uv[1]);
+        triS[4 * i + 2] = make_float4(t.nrm[6], t.nrm[7], t.nrm[8], t.uv[2]);
+        triS[4 * i + 3] = make_float4(t.uv[3], t.uv[4], t.uv[5], 0.f);
+        triMat[i] = t.mat;
+    }
+    std::vector<float4> mats(sc.materials.size() * 2);
+    for (size_t i = 0; i < sc.materials.size(); i++) {
+        const rt::HostMaterial& m = sc.materials[i];
+        mats[2 * i] = make_float4(m.r, m.g, m.b, m.param);
+        int k[4] = {m.kind, m.tex_d, m.tex_r, m.tex_n};
+        float4 f;
+        std::memcpy(&f, k, 16);
+        mats[2 * i + 1] = f;
+    }
+    std::vector<uint32_t> texels;
+    std::vector<int4> texDesc(sc.textures.size());
+    for (size_t i = 0; i < sc.textures.size(); i++) {
+        const rt::HostTexture& t = sc.textures[i];
+        texDesc[i] = make_int4((int)texels.size(), t.w, t.h, 0);
+        size_t n = (size_t)t.w * t.h, base = texels.size();
+        if (base + n > (size_t)0x7FFFFFFF) return fail(RT_ERR_LIMIT, "texture pool beyond 2^31 texels");
+        texels.resize(base + n);
+        for (size_t p = 0; p < n; p++)
+            texels[base + p] = (uint32_t)t.rgb[3 * p] | ((uint32_t)t.rgb[3 * p + 1] << 8) | ((uint32_t)t.rgb[3 * p + 2] << 16);
+    }
+    // stbi_loadf's 8-bit -> float map: (float)(pow(byte / 255.0f, 2.2f) * 1.0f) with float operands
+    // (R/vendor/stb_image/stb_image.h:1553,1851), applied per channel at sampling time.
+    std::vector<float> lut(256);
+    for (int i = 0; i < 256; i++) lut[i] = (float)(std::pow(i / 255.0f, 2.2f) * 1.0f);
+
+    rt::DevScene d{};
+    int rc;
+    std::vector<float4> nodes(sc.flat.nodes.size() / 4);
+    std::memcpy(nodes.data(), sc.flat.nodes.data(), sc.flat.nodes.size() * 4);
+    if ((rc = devUpload(ctx, nodes, &d.nodes))) return rc;
+    if ((rc = devUpload(ctx, sc.flat.prim_refs, &d.prim_refs))) return rc;
+    if ((rc = devUpload(ctx, spheres, &d.spheres))) return rc;
+    if ((rc = devUpload(ctx, sphereMat, &d.sphere_mat))) return rc;
+    if ((rc = devUpload(ctx, triI, &d.tri_isect))) return rc;
+    if ((rc = devUpload(ctx, triS, &d.tri_shade))) return rc;
+    if ((rc = devUpload(ctx, triMat, &d.tri_mat))) return rc;
+    if ((rc = devUpload(ctx, mats, &d.materials))) return rc;
+    if ((rc = devUpload(ctx, texels, &d.texels))) return rc;
+    if ((rc = devUpload(ctx, texDesc, &d.tex_desc))) return rc;
+    if ((rc = devUpload(ctx, lut, &d.lut))) return rc;
+    d.n_nodes = nNodes;
+    d.n_prim_refs = (int)sc.flat.prim_refs.size();
+    d.n_spheres = (int)sc.spheres.size();
+    d.n_tris = (int)sc.triangles.size();
+    std::memcpy(d.cam, &sc.camera, sizeof(float) * 22);
+    std::memcpy(d.bg, sc.background, sizeof(float) * 3);
+    ctx->dsc = d;
+    ctx->lds_need = rt::ldsSceneBytes(d.n_nodes, d.n_prim_refs, d.n_spheres, d.n_tris);
+    ctx->use_lds = ctx->lds_need <= kMaxLdsScene && envInt("RT_LDS", 1) != 0;
+    ctx->scene_loaded = true;
+    return RT_OK;
+}
+
+size_t rt_accum_bytes(int width, int height, int world) {
+    if (width <= 0 || height <= 0 || world <= 0) return 0;
+    int tx, ty, tprl;
+    tileGeometry(width, height, world, &tx, &ty, &tprl);
+    return (size_t)ty * tprl * 64 * sizeof(float4);
+}
+
+static int setTarget(rt_context* ctx, int width, int height, int rank, int world, void* external) {
+    if (!ctx) return fail(RT_ERR_INVALID, "null context");
+    if (width < 2 || height < 2) return fail(RT_ERR_INVALID, "image must be at least 2x2 (the pixel map divides by W-1, H-1)");
+    if (world < 1 || rank < 0 || rank >= world) return fail(RT_ERR_INVALID, "bad rank / world");
+    if ((long long)width * height > (1ll << 30)) return fail(RT_ERR_LIMIT, "image beyond 2^30 pixels");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    freeTarget(ctx);
+    ctx->width = width;
+    ctx->height = height;
+    ctx->rank = rank;
+    ctx->world = world;
+    tileGeometry(width, height, world, &ctx->tiles_x, &ctx->tiles_y, &ctx->tprl);
+    ctx->n_local_tiles = ctx->tiles_y * ctx->tprl;
+    if (external) {
+        ctx->accum = reinterpret_cast<float4*>(external);
+        ctx->accum_owned = false;
+    } else {
+        HIP_TRY(hipMalloc((void**)&ctx->accum, rt_accum_bytes(width, height, world)));
+        ctx->accum_owned = true;
+        HIP_TRY(hipMemsetAsync(ctx->accum, 0, rt_accum_bytes(width, height, world), ctx->stream));
+    }
+    return RT_OK;
+}
+int rt_set_target(rt_context* ctx, int width, int height, int rank, int world) {
+    return setTarget(ctx, width, height, rank, world, nullptr);
+}
+int rt_set_target_external(rt_context* ctx, int width, int height, int rank, int world, void* device_accum) {
+    if (!device_accum) return fail(RT_ERR_INVALID, "null accumulation buffer");
+    return setTarget(ctx, width, height, rank, world, device_accum);
+}
+
+int rt_clear(rt_context* ctx) {
+    if (!ctx || !ctx->accum) return fail(RT_ERR_STATE, "rt_set_target() has not been called");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemsetAsync(ctx->accum, 0, rt_accum_bytes(ctx->width, ctx->height, ctx->world), ctx->stream));
+    return RT_OK;
+}
+
+int rt_render(rt_context* ctx, int first_sample, int n_samples, int max_depth) {
+    int rc = checkRenderState(ctx);
+    if (rc) return rc;
+    if (first_sample < 0 || n_samples < 0) return fail(RT_ERR_INVALID, "negative sample range");
+    if ((long long)first_sample + n_samples > (1 << 24))
+        return fail(RT_ERR_LIMIT, "sample index beyond 2^24 (the RNG key is the sample index as a float)");
+    if (n_samples == 0) return RT_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    rt::RenderArgs a = makeArgs(ctx, first_sample, n_samples, max_depth);
+    HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+    rc = launch(ctx, a, false);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+    ctx->timed = true;
+    return RT_OK;
+}
+
+int rt_sync(rt_context* ctx) {
+    if (!ctx) return fail(RT_ERR_INVALID, "null context");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int rt_cancel(rt_context* ctx) {
+    if (!ctx) return fail(RT_ERR_INVALID, "null context");
+    ctx->cancel.store(1);
+    return RT_OK;
+}
+
+int rt_run(rt_context* ctx, int samples_per_pixel, int samples_per_pass, int max_depth, rt_pass_callback on_pass,
+           void* user) {
+    int rc = checkRenderState(ctx);
+    if (rc) return rc;
+    if (samples_per_pixel < 0 || samples_per_pass < 1) return fail(RT_ERR_INVALID, "bad sample counts");
+    ctx->cancel.store(0);
+    rc = rt_clear(ctx);
+    if (rc) return rc;
+    int done = 0;
+    while (done < samples_per_pixel) {
+        if (ctx->cancel.load()) return fail(RT_ERR_CANCELLED, "render cancelled");
+        int n = std::min(samples_per_pass, samples_per_pixel - done);
+        rc = rt_render(ctx, done, n, max_depth);
+        if (rc) return rc;
+        rc = rt_sync(ctx);
+        if (rc) return rc;
+        done += n;
+        if (on_pass) on_pass(done, user);
+    }
+    return RT_OK;
+}
+
+static int readResolved(rt_context* ctx, int mode, int spp, void* dst, size_t bytes) {
+    int rc = checkRenderState(ctx);
+    if (rc) return rc;
+    if (!dst) return fail(RT_ERR_INVALID, "null destination");
+    HIP_TRY(hipSetDevice(ctx->device));
+    void* d = nullptr;
+    HIP_TRY(hipMalloc(&d, bytes));
+    const int only = ctx->world > 1 ? ctx->rank : -1;
+    hipError_t e = rt::launchResolve(ctx->accum, 0, ctx->width, ctx->height, ctx->tprl, ctx->world, only, mode, spp,
+                                     reinterpret_cast<float4*>(d), reinterpret_cast<uint32_t*>(d), ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dst, d, bytes, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(RT_ERR_HIP, std::string("resolve: ") + hipGetErrorString(e));
+    return RT_OK;
+}
+int rt_read_accum_rgba32f(rt_context* ctx, float* dst) {
+    if (!ctx) return fail(RT_ERR_INVALID, "null context");
+    return readResolved(ctx, 0, 1, dst, (size_t)ctx->width * ctx->height * 16);
+}
+int rt_read_rgba8(rt_context* ctx, int samples_per_pixel, uint8_t* dst) {
+    if (!ctx) return fail(RT_ERR_INVALID, "null context");
+    if (samples_per_pixel < 1) return fail(RT_ERR_INVALID, "samples_per_pixel must be positive");
+    return readResolved(ctx, 1, samples_per_pixel, dst, (size_t)ctx->width * ctx->height * 4);
+}
+
+int rt_resolve_gathered(rt_context* ctx, const void* device_payloads, int world, void* device_rgba32f) {
+    if (!ctx || !device_payloads || !device_rgba32f) return fail(RT_ERR_INVALID, "null argument");
+    if (world != ctx->world) return fail(RT_ERR_INVALID, "world differs from rt_set_target()");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t stride4 = rt_accum_bytes(ctx->width, ctx->height, world) / sizeof(float4);
+    HIP_TRY(rt::launchResolve(reinterpret_cast<const float4*>(device_payloads), stride4, ctx->width, ctx->height,
+                              ctx->tprl, world, -1, 0, 1, reinterpret_cast<float4*>(device_rgba32f), nullptr,
+                              ctx->stream));
+    return RT_OK;
+}
+
+int rt_trace(rt_context* ctx, int n, const float* rays6, int32_t* prim_kind, int32_t* prim_id, float* t, float* normal3,
+             int32_t* front_face, float* uv2) {
+    if (!ctx || !ctx->scene_loaded) return fail(RT_ERR_STATE, "rt_upload_scene() has not been called");
+    if (n < 0 || (n && (!rays6 || !prim_kind || !prim_id || !t))) return fail(RT_ERR_INVALID, "bad arguments");
+    if (n == 0) return RT_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t N = (size_t)n;
+    char* d = nullptr;
+    // rays 24N | kind 4N | id 4N | t 4N | normal 12N | front 4N | uv 8N
+    HIP_TRY(hipMalloc((void**)&d, 60 * N));
+    float* dRays = (float*)d;
+    int* dKind = (int*)(d + 24 * N);
+    int* dId = (int*)(d + 28 * N);
+    float* dT = (float*)(d + 32 * N);
+    float* dN = (float*)(d + 36 * N);
+    int* dF = (int*)(d + 48 * N);
+    float* dUv = (float*)(d + 52 * N);
+    hipError_t e = hipMemcpyAsync(dRays, rays6, 24 * N, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = rt::launchTrace(ctx->dsc, n, dRays, dKind, dId, dT, dN, dF, dUv, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(prim_kind, dKind, 4 * N, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(prim_id, dId, 4 * N, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(t, dT, 4 * N, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && normal3) e = hipMemcpyAsync(normal3, dN, 12 * N, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && front_face) e = hipMemcpyAsync(front_face, dF, 4 * N, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && uv2) e = hipMemcpyAsync(uv2, dUv, 8 * N, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(RT_ERR_HIP, std::string("trace: ") + hipGetErrorString(e));
+    return RT_OK;
+}
+
+int rt_scatter_test(rt_context* ctx, int n, const int32_t* material, const float* ray_in6, const float* p3,
+                    const float* normal3, const int32_t* front_face, const float* uv2, const uint32_t* key4,
+                    float* atten3, float* ray_out6, int32_t* alive, uint32_t* counter_out) {
+    if (!ctx || !ctx->scene_loaded) return fail(RT_ERR_STATE, "rt_upload_scene() has not been called");
+    if (n <= 0 || !material || !ray_in6 || !p3 || !normal3 || !front_face || !uv2 || !key4 || !atten3 || !ray_out6 ||
+        !alive || !counter_out)
+        return fail(RT_ERR_INVALID, "bad arguments");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t N = (size_t)n;
+    // in: mat 4 | ray 24 | p 12 | n 12 | front 4 | uv 8 | key 16 = 80 ; out: atten 12 | ray 24 | alive 4 | counter 4 = 44
+    char* d = nullptr;
+    HIP_TRY(hipMalloc((void**)&d, 124 * N));
+    char* q = d;
+    auto take = [&](size_t bytes) {
+        char* r = q;
+        q += bytes * N;
+        return r;
+    };
+    int* dMat = (int*)take(4);
+    float* dRay = (float*)take(24);
+    float* dP = (float*)take(12);
+    float* dN = (float*)take(12);
+    int* dF = (int*)take(4);
+    float* dUv = (float*)take(8);
+    unsigned int* dKey = (unsigned int*)take(16);
+    float* dAtt = (float*)take(12);
+    float* dOut = (float*)take(24);
+    int* dAlive = (int*)take(4);
+    unsigned int* dCnt = (unsigned int*)take(4);
+    hipError_t e = hipMemcpyAsync(dMat, material, 4 * N, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dRay, ray_in6, 24 * N, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dP, p3, 12 * N, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dN, normal3, 12 * N, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dF, front_face, 4 * N, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dUv, uv2, 8 * N, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dKey, key4, 16 * N, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess)
+        e = rt::launchScatter(ctx->dsc, n, dMat, dRay, dP, dN, dF, dUv, dKey, dAtt, dOut, dAlive, dCnt, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(atten3, dAtt, 12 * N, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(ray_out6, dOut, 24 * N, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(alive, dAlive, 4 * N, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(counter_out, dCnt, 4 * N, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(RT_ERR_HIP, std::string("scatter test: ") + hipGetErrorString(e));
+    return RT_OK;
+}
+
+int rt_count(rt_context* ctx, int first_sample, int n_samples, int max_depth, rt_counters* out) {
+    int rc = checkRenderState(ctx);
+    if (rc) return rc;
+    if (!out || first_sample < 0 || n_samples < 1) return fail(RT_ERR_INVALID, "bad arguments");
+    HIP_TRY(hipSetDevice(ctx->device));
+    // counting must not disturb the image: run it on a scratch copy of the accumulation buffer
+    const size_t bytes = rt_accum_bytes(ctx->width, ctx->height, ctx->world);
+    float4* scratch = nullptr;
+    HIP_TRY(hipMalloc((void**)&scratch, bytes));
+    hipError_t e = hipMemsetAsync(scratch, 0, bytes, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(ctx->counters, 0, 13 * sizeof(unsigned long long), ctx->stream);
+    int rcl = RT_OK;
+    if (e == hipSuccess) {
+        rt::RenderArgs a = makeArgs(ctx, first_sample, n_samples, max_depth);
+        a.accum = scratch;
+        rcl = launch(ctx, a, true);
+    }
+    unsigned long long host[13] = {0};
+    if (e == hipSuccess && rcl == RT_OK)
+        e = hipMemcpyAsync(host, ctx->counters, sizeof host, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(scratch);
+    if (rcl) return rcl;
+    if (e != hipSuccess) return fail(RT_ERR_HIP, std::string("count: ") + hipGetErrorString(e));
+    out->samples = host[0];
+    out->rays = host[1];
+    out->node_tests = host[2];
+    out->sphere_tests = host[3];
+    out->tri_tests = host[4];
+    out->hits = host[5];
+    out->scatter_lambertian = host[6];
+    out->scatter_metal = host[7];
+    out->scatter_dielectric = host[8];
+    out->scatter_light = host[9];
+    out->scatter_pbr = host[10];
+    out->misses = host[11];
+    out->depth_cutoffs = host[12];
+    return RT_OK;
+}
+
+int rt_last_render_ms(rt_context* ctx, float* ms) {
+    if (!ctx || !ms) return fail(RT_ERR_INVALID, "bad arguments");
+    if (!ctx->timed) return fail(RT_ERR_STATE, "no rt_render() has been issued");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipEventSynchronize(ctx->ev1));
+    HIP_TRY(hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+    return RT_OK;
+}
+
+void* rt_stream(rt_context* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+}  // extern "C"

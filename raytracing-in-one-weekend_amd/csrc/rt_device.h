@@ -1,0 +1,50 @@
+// Device-side data layout shared by the host upload code and the HIP kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rt {
+
+// Where each array of the flattened scene lives in HBM.  Everything is read-only during
+// a render and small enough for the cover scene to be staged whole into LDS.
+struct DevScene {
+    const float4* nodes;      // 2 x float4 per entry: {min.xyz, skip|flags}, {max.xyz, first_ref}
+    const uint32_t* prim_refs;
+    const float4* spheres;    // {c.xyz, r}
+    const int* sphere_mat;
+    const float4* tri_isect;  // 3 x float4 per triangle: {v0.xyz, -}, {edge1.xyz, -}, {edge2.xyz, -}
+    const float4* tri_shade;  // 4 x float4: {n0.xyz, uv0.x}, {n1.xyz, uv0.y}, {n2.xyz, uv1.x}, {uv1.y, uv2.x, uv2.y, -}
+    const int* tri_mat;
+    const float4* materials;  // 2 x float4: {r, g, b, param}, {kind, texD, texR, texN} (ints bit-cast)
+    const uint32_t* texels;   // all textures, RGBX8, one dword per texel
+    const int4* tex_desc;     // {first texel, width, height, 0}
+    const float* lut;         // 256-entry 8-bit -> float map
+    int n_nodes, n_prim_refs, n_spheres, n_tris;
+    float cam[22];            // origin, lowerLeftCorner, horizontal, vertical, u, v, w, lensRadius
+    float bg[3];
+};
+
+struct RenderArgs {
+    DevScene sc;
+    float4* accum;        // tiled: [local tile][lane] -> {r, g, b, samples}
+    unsigned int* queue;  // next-tile counter for the persistent launch shape (may be null)
+    unsigned long long* counters;  // 13 path statistics (counting launches only)
+    int width, height;
+    int tiles_x, tiles_y;      // 8x8-pixel tiles
+    int tiles_per_row_local;   // owned tiles per tile row = ceil(tiles_x / world)
+    int n_local_tiles;
+    int rank, world;
+    int first_sample, n_samples, max_depth;
+    int lds_bytes;
+};
+
+constexpr int kTile = 8;  // one wave64 = one 8x8 pixel tile
+
+// Bytes of LDS the staged traversal data needs (nodes, leaf references, spheres, triangle
+// intersection records), each block 16-byte aligned.
+inline size_t ldsSceneBytes(int n_nodes, int n_refs, int n_spheres, int n_tris) {
+    auto al = [](size_t x) { return (x + 15) & ~size_t(15); };
+    return al((size_t)n_nodes * 32) + al((size_t)n_refs * 4) + al((size_t)n_spheres * 16) + al((size_t)n_tris * 48);
+}
+
+}  // namespace rt

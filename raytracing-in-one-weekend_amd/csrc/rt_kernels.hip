@@ -1,0 +1,630 @@
+// HIP kernels of the path tracer core for gfx950 (wave64).
+//
+// One lane owns one pixel and walks through that pixel's samples in order, so every
+// pixel's float sum is formed in the same order as the reference's `pixelColor +=`
+// loop (R/src/Core/Raytracer.cpp:84-90) and no atomics touch the image.  One wave owns
+// an 8x8 pixel tile.  Arithmetic follows the reference expression by expression
+// (build with -ffp-contract=off; fp32 divide and sqrt are correctly rounded).
+// R/ = /root/reference/Raytracing-In-A-Weekend/.
+#include "rt_device.h"
+
+namespace rt {
+
+constexpr uint32_t kNoBox = 1u << 30;
+constexpr uint32_t kSkipMask = kNoBox - 1;
+constexpr uint32_t kRefLast = 1u << 31;
+constexpr uint32_t kRefTri = 1u << 30;
+constexpr uint32_t kRefId = kRefTri - 1;
+constexpr uint32_t kNoHit = 0xFFFFFFFFu;
+constexpr float kTMin = 0.001f;  // R/src/Core/Raytracer.cpp:10
+
+__device__ __forceinline__ uint32_t fbits(float f) { return __float_as_uint(f); }
+
+// R/assets/shaders/raytracer.comp:35-42
+__device__ __forceinline__ uint32_t hashu(uint32_t x) {
+    x += (x << 10u);
+    x ^= (x >> 6u);
+    x += (x << 3u);
+    x ^= (x >> 11u);
+    x += (x << 15u);
+    return x;
+}
+
+// R/assets/shaders/raytracer.comp:44-58.  The shader hashes
+// floatBitsToUint(vec4(x, y, sampleCount, counter)) as v.x ^ hash(v.y) ^ hash(v.z) ^ hash(v.w);
+// the first three terms are constant for one pixel-sample and are folded into `key`.
+struct Rng {
+    uint32_t key, counter;
+    __device__ __forceinline__ void init(uint32_t px, uint32_t py, int sample) {
+        key = fbits((float)px) ^ hashu(fbits((float)py)) ^ hashu(fbits((float)sample));
+        counter = 0;
+    }
+    __device__ __forceinline__ float next() {
+        counter += 1;
+        uint32_t m = hashu(key ^ hashu(fbits((float)counter)));
+        m &= 0x007FFFFFu;
+        m |= 0x3F800000u;
+        return __uint_as_float(m) - 1.0f;
+    }
+    // randomFloat(min, max), R/src/Core/RTWeekend.h:33-36
+    __device__ __forceinline__ float next(float mn, float mx) { return mn + (mx - mn) * next(); }
+};
+
+struct V3 {
+    float x, y, z;
+};
+__device__ __forceinline__ float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+__device__ __forceinline__ V3 cross(V3 a, V3 b) {
+    return {a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y};
+}
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 operator*(V3 a, V3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
+__device__ __forceinline__ V3 operator*(float s, V3 a) { return {s * a.x, s * a.y, s * a.z}; }
+__device__ __forceinline__ V3 operator*(V3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ V3 operator/(V3 a, float s) { return {a.x / s, a.y / s, a.z / s}; }
+__device__ __forceinline__ V3 operator-(V3 a) { return {-a.x, -a.y, -a.z}; }
+__device__ __forceinline__ V3 normalize(V3 v) { return v * (1.0f / sqrtf(dot(v, v))); }
+__device__ __forceinline__ V3 reflect(V3 I, V3 N) { return I - N * dot(N, I) * 2.0f; }
+
+// randomVecInUnitSphere, R/src/Core/RTWeekend.cpp:3-12 (z, y, x draw order of the g++ build)
+__device__ __forceinline__ V3 randomInUnitSphere(Rng& rng) {
+    for (;;) {
+        float z = rng.next(-1.0f, 1.0f), y = rng.next(-1.0f, 1.0f), x = rng.next(-1.0f, 1.0f);
+        V3 p{x, y, z};
+        if (dot(p, p) >= 1.0f) continue;
+        return p;
+    }
+}
+
+// Scene arrays as the traversal sees them: either straight from HBM/L2 or staged in LDS.
+struct SceneView {
+    const float4* nodes;
+    const uint32_t* refs;
+    const float4* spheres;
+    const float4* tris;
+};
+
+struct Stats {
+    unsigned long long v[13];
+};
+enum { C_SAMPLES, C_RAYS, C_NODE, C_SPHERE, C_TRI, C_HITS, C_LAMB, C_METAL, C_DIEL, C_LIGHT, C_PBR, C_MISS, C_CUTOFF };
+
+struct Ray {
+    V3 o, d;
+};
+
+struct Hit {
+    float t;
+    uint32_t ref;  // kNoHit or the leaf reference (triangle flag + id)
+    float bu, bv;  // barycentrics of the accepted triangle hit
+};
+
+// Closest hit along the threaded, reference-ordered node array.  Entry i: box test with the
+// running closest distance as tMax (AABB::Hit, R/src/AccelerationStructures/AABB.h:10-24;
+// BVHNode::Hit passes rec.t of the left child on to the right one, Bvh.h:84-85, which is the
+// running closest hit); on a miss jump to `skip`, else test the entry's leaf run and go to
+// i + 1.  A later primitive wins a tie in t (`tMax < t` rejects, equality accepts).
+template <bool COUNT>
+__device__ __forceinline__ Hit traverse(const SceneView& sv, int n_nodes, const Ray& r, Stats* st) {
+    Hit h;
+    h.t = __builtin_inff();
+    h.ref = kNoHit;
+    h.bu = 0.0f;
+    h.bv = 0.0f;
+    const float invx = 1.0f / r.d.x, invy = 1.0f / r.d.y, invz = 1.0f / r.d.z;
+    const float a = dot(r.d, r.d);
+    int idx = 0;
+    while (idx < n_nodes) {
+        const float4 n0 = sv.nodes[2 * idx], n1 = sv.nodes[2 * idx + 1];
+        const uint32_t w3 = fbits(n0.w);
+        const int first = (int)fbits(n1.w);
+        bool pass = true;
+        if (!(w3 & kNoBox)) {
+            if (COUNT) st->v[C_NODE]++;
+            float tmin = kTMin, tmax = h.t;
+            float t0 = (n0.x - r.o.x) * invx, t1 = (n1.x - r.o.x) * invx;
+            if (invx < 0.0f) { float s = t0; t0 = t1; t1 = s; }
+            tmin = t0 > tmin ? t0 : tmin;
+            tmax = t1 < tmax ? t1 : tmax;
+            bool fail = tmax <= tmin;
+            t0 = (n0.y - r.o.y) * invy; t1 = (n1.y - r.o.y) * invy;
+            if (invy < 0.0f) { float s = t0; t0 = t1; t1 = s; }
+            tmin = t0 > tmin ? t0 : tmin;
+            tmax = t1 < tmax ? t1 : tmax;
+            fail = fail || (tmax <= tmin);
+            t0 = (n0.z - r.o.z) * invz; t1 = (n1.z - r.o.z) * invz;
+            if (invz < 0.0f) { float s = t0; t0 = t1; t1 = s; }
+            tmin = t0 > tmin ? t0 : tmin;
+            tmax = t1 < tmax ? t1 : tmax;
+            fail = fail || (tmax <= tmin);
+            pass = !fail;
+        }
+        if (pass) {
+            if (first >= 0) {
+                int p = first;
+                uint32_t ref;
+                do {
+                    ref = sv.refs[p++];
+                    const uint32_t id = ref & kRefId;
+                    if (ref & kRefTri) {
+                        // Triangle::Hit, R/src/Core/Hittable.h:58-141 (edges are precomputed on the
+                        // host with the same two subtractions)
+                        if (COUNT) st->v[C_TRI]++;
+                        const float4 q0 = sv.tris[3 * id], q1 = sv.tris[3 * id + 1], q2 = sv.tris[3 * id + 2];
+                        const V3 v0{q0.x, q0.y, q0.z}, e1{q1.x, q1.y, q1.z}, e2{q2.x, q2.y, q2.z};
+                        const float EPS = 1e-8f;
+                        V3 hh = cross(r.d, e2);
+                        float det = dot(e1, hh);
+                        if (!(det > -EPS && det < EPS)) {
+                            float f = 1.0f / det;
+                            V3 s = r.o - v0;
+                            float u = f * dot(s, hh);
+                            if (!(u < 0.0f || u > 1.0f)) {
+                                V3 q = cross(s, e1);
+                                float v = f * dot(r.d, q);
+                                if (!(v < 0.0f || u + v > 1.0f)) {
+                                    float t = f * dot(e2, q);
+                                    if (!(t < kTMin || h.t < t) && (t > EPS)) {
+                                        h.t = t;
+                                        h.ref = ref & ~kRefLast;
+                                        h.bu = u;
+                                        h.bv = v;
+                                    }
+                                }
+                            }
+                        }
+                    } else {
+                        // Sphere::Hit, R/src/Core/Hittable.h:228-255
+                        if (COUNT) st->v[C_SPHERE]++;
+                        const float4 s = sv.spheres[id];
+                        V3 oc{r.o.x - s.x, r.o.y - s.y, r.o.z - s.z};
+                        float halfB = dot(oc, r.d);
+                        float c = dot(oc, oc) - s.w * s.w;
+                        float disc = halfB * halfB - a * c;
+                        if (!(disc < 0)) {
+                            float sq = sqrtf(disc);
+                            float root = (-halfB - sq) / a;
+                            bool ok = true;
+                            if (root < kTMin || h.t < root) {
+                                root = (-halfB + sq) / a;
+                                if (root < kTMin || h.t < root) ok = false;
+                            }
+                            if (ok) {
+                                h.t = root;
+                                h.ref = ref & ~kRefLast;
+                            }
+                        }
+                    }
+                } while (!(ref & kRefLast));
+            }
+            idx = idx + 1;
+        } else {
+            idx = (int)(w3 & kSkipMask);
+        }
+    }
+    return h;
+}
+
+struct Surface {
+    V3 p, n;
+    bool front;
+    float u, v;
+    int mat;
+};
+
+// The HitRecord fields of the closest hit, computed once after traversal from (primitive, t):
+// same expressions as Sphere::Hit (Hittable.h:248-252) and Triangle::Hit (Hittable.h:86-107).
+__device__ __forceinline__ Surface surfaceAt(const DevScene& sc, const SceneView& sv, const Ray& r, const Hit& h) {
+    Surface s;
+    s.p = r.o + h.t * r.d;
+    s.u = 0.0f;
+    s.v = 0.0f;
+    s.front = false;
+    const uint32_t id = h.ref & kRefId;
+    if (h.ref & kRefTri) {
+        const float4 q1 = sv.tris[3 * id + 1], q2 = sv.tris[3 * id + 2];
+        const float4 a0 = sc.tri_shade[4 * id], a1 = sc.tri_shade[4 * id + 1], a2 = sc.tri_shade[4 * id + 2],
+                     a3 = sc.tri_shade[4 * id + 3];
+        const V3 n0{a0.x, a0.y, a0.z}, n1{a1.x, a1.y, a1.z}, n2{a2.x, a2.y, a2.z};
+        const float u = h.bu, v = h.bv;
+        if (n0.x == 0.0f && n0.y == 0.0f && n0.z == 0.0f) {
+            V3 e1{q1.x, q1.y, q1.z}, e2{q2.x, q2.y, q2.z};
+            V3 outward = normalize(cross(e2, e1));
+            s.front = dot(r.d, outward) < 0;
+            s.n = s.front ? outward : -outward;
+        } else {
+            // u weighs vertex 0, v vertex 1, (1-u-v) vertex 2, as the reference does
+            s.n = normalize(u * n0 + v * n1 + (1 - u - v) * n2);
+        }
+        const float uv0x = a0.w, uv0y = a1.w, uv1x = a2.w, uv1y = a3.x, uv2x = a3.y, uv2y = a3.z;
+        if (uv0x != -1.0f) {
+            s.u = (u * uv0x + v * uv1x) + (1 - u - v) * uv2x;
+            s.v = (u * uv0y + v * uv1y) + (1 - u - v) * uv2y;
+        } else {
+            s.u = u;
+            s.v = v;
+        }
+        s.mat = sc.tri_mat[id];
+    } else {
+        const float4 sp = sv.spheres[id];
+        V3 c{sp.x, sp.y, sp.z};
+        V3 outward = (s.p - c) / sp.w;
+        s.front = dot(r.d, outward) < 0;
+        s.n = s.front ? outward : -outward;
+        s.mat = sc.sphere_mat[id];
+    }
+    return s;
+}
+
+// Texture::At, R/src/Material/Texture.h:37-43: nearest texel, row stride = height, and the
+// 8-bit -> float map of stbi_loadf.  Out-of-range indices are clamped (the reference reads
+// out of bounds there).
+__device__ __forceinline__ V3 textureAt(const DevScene& sc, int tex, float u, float v) {
+    const int4 d = sc.tex_desc[tex];
+    int tx = (int)((u * d.y) - 0.5f);
+    int ty = (int)(((1 - v) * d.z) - 0.5f);
+    long long idx = (long long)ty * d.z + tx;
+    const long long n = (long long)d.y * d.z;
+    idx = idx < 0 ? 0 : (idx >= n ? n - 1 : idx);
+    const uint32_t px = sc.texels[(size_t)d.x + (size_t)idx];
+    return {sc.lut[px & 255u], sc.lut[(px >> 8) & 255u], sc.lut[(px >> 16) & 255u]};
+}
+
+// Material::scatter for the five material kinds (R/src/Material/Material.h:22-160).
+// Returns true if the path continues with `out` and `atten`; false ends it with `emit`.
+template <bool COUNT>
+__device__ __forceinline__ bool scatter(const DevScene& sc, const Ray& in, const Surface& s, Rng& rng, Ray& out,
+                                        V3& atten, V3& emit, Stats* st) {
+    const float4 m0 = sc.materials[2 * s.mat], m1 = sc.materials[2 * s.mat + 1];
+    const int kind = (int)fbits(m1.x);
+    emit = {0.0f, 0.0f, 0.0f};
+    out.o = s.p;
+    if (kind == 0) {  // Lambertian, Material.h:22-36
+        if (COUNT) st->v[C_LAMB]++;
+        V3 dir = s.n + normalize(randomInUnitSphere(rng));
+        // vecNearZero, R/src/Core/RTWeekend.cpp:39-43 (threshold 1e-8 as a double)
+        if (((double)fabsf(dir.x) < 1e-8) && ((double)fabsf(dir.y) < 1e-8) && ((double)fabsf(dir.z) < 1e-8)) dir = s.n;
+        out.d = dir;
+        atten = {m0.x, m0.y, m0.z};
+        return true;
+    }
+    if (kind == 1) {  // Metal, Material.h:47-53
+        if (COUNT) st->v[C_METAL]++;
+        V3 reflected = reflect(normalize(in.d), s.n);
+        out.d = reflected + m0.w * randomInUnitSphere(rng);
+        atten = {m0.x, m0.y, m0.z};
+        return dot(out.d, s.n) > 0;
+    }
+    if (kind == 2) {  // Dielectric, Material.h:65-95
+        if (COUNT) st->v[C_DIEL]++;
+        atten = {1.0f, 1.0f, 1.0f};
+        const float ir = m0.w;
+        float ratio = s.front ? (1.0f / ir) : ir;
+        V3 unit = normalize(in.d);
+        float cosTheta = fminf(dot(-unit, s.n), 1.0f);
+        float sinTheta = sqrtf(1.0f - cosTheta * cosTheta);
+        bool reflectIt = ratio * sinTheta > 1.0f;
+        if (!reflectIt) {
+            // Schlick: r0 + (1 - r0) * pow(1 - cos, 5), evaluated in double as in the reference
+            float r0 = (1 - ratio) / (1 + ratio);
+            r0 = r0 * r0;
+            double x = (double)(1 - cosTheta);
+            double x2 = x * x;
+            double x5 = x2 * x2 * x;
+            float refl = (float)((double)r0 + (double)(1 - r0) * x5);
+            reflectIt = refl > rng.next();
+        }
+        if (reflectIt) {
+            out.d = reflect(unit, s.n);
+        } else {  // refract, R/src/Core/RTWeekend.cpp:45-51
+            float ct = fminf(dot(-unit, s.n), 1.0f);
+            V3 perp = ratio * (unit + ct * s.n);
+            V3 par = -sqrtf(fabsf(1.0f - dot(perp, perp))) * s.n;
+            out.d = perp + par;
+        }
+        return true;
+    }
+    if (kind == 3) {  // DiffuseLight, Material.h:103-110
+        if (COUNT) st->v[C_LIGHT]++;
+        emit = {m0.x, m0.y, m0.z};
+        return false;
+    }
+    // PBRMaterial, Material.h:121-160.  The normal-map result is overwritten by rec.normal
+    // at :140, so only the diffuse and roughness maps influence the path.
+    if (COUNT) st->v[C_PBR]++;
+    const int texD = (int)fbits(m1.y), texR = (int)fbits(m1.z);
+    atten = textureAt(sc, texD, s.u, s.v);
+    if (texR >= 0) {
+        V3 reflected = reflect(normalize(in.d), s.n);
+        V3 rough = textureAt(sc, texR, s.u, s.v);
+        out.d = reflected + rough * randomInUnitSphere(rng);
+        return dot(out.d, s.n) > 0;
+    }
+    V3 dir = s.n + normalize(randomInUnitSphere(rng));
+    if (((double)fabsf(dir.x) < 1e-8) && ((double)fabsf(dir.y) < 1e-8) && ((double)fabsf(dir.z) < 1e-8)) dir = s.n;
+    out.d = dir;
+    return true;
+}
+
+// Camera::GetRay, R/src/Core/Camera.h:27-33, with randomInUnitDisk (RTWeekend.cpp:29-37; y is
+// drawn before x in the g++ build).  The disk is sampled even when lensRadius is 0.
+__device__ __forceinline__ Ray cameraRay(const DevScene& sc, float s, float t, Rng& rng) {
+    const float* c = sc.cam;
+    float px, py;
+    for (;;) {
+        py = rng.next(-1.0f, 1.0f);
+        px = rng.next(-1.0f, 1.0f);
+        if ((px * px + py * py) + 0.0f * 0.0f >= 1) continue;
+        break;
+    }
+    const float lr = c[21];
+    const float rdx = lr * px, rdy = lr * py;
+    const V3 org{c[0], c[1], c[2]}, llc{c[3], c[4], c[5]}, hor{c[6], c[7], c[8]}, ver{c[9], c[10], c[11]};
+    const V3 cu{c[12], c[13], c[14]}, cv{c[15], c[16], c[17]};
+    V3 offset = cu * rdx + cv * rdy;
+    Ray r;
+    r.o = org + offset;
+    r.d = llc + s * hor + t * ver - org - offset;
+    return r;
+}
+
+// rayColor, R/src/Core/Raytracer.cpp:3-20, unrolled into a loop.  The attenuation product is
+// accumulated front to back (throughput) and multiplied into the terminal radiance; no
+// reference material both emits and scatters, so this is the recursion's value up to the
+// association order of the float products.
+template <bool COUNT>
+__device__ __forceinline__ V3 rayColor(const DevScene& sc, const SceneView& sv, Ray r, int depth, Rng& rng, Stats* st) {
+    V3 throughput{1.0f, 1.0f, 1.0f};
+    for (;;) {
+        if (depth <= 0) {
+            if (COUNT) st->v[C_CUTOFF]++;
+            return throughput * V3{0.0f, 0.0f, 0.0f};
+        }
+        if (COUNT) st->v[C_RAYS]++;
+        Hit h = traverse<COUNT>(sv, sc.n_nodes, r, st);
+        if (h.ref == kNoHit) {
+            if (COUNT) st->v[C_MISS]++;
+            return throughput * V3{sc.bg[0], sc.bg[1], sc.bg[2]};
+        }
+        if (COUNT) st->v[C_HITS]++;
+        Surface s = surfaceAt(sc, sv, r, h);
+        Ray out;
+        V3 atten, emit;
+        if (!scatter<COUNT>(sc, r, s, rng, out, atten, emit, st)) return throughput * emit;
+        throughput = throughput * atten;
+        r = out;
+        depth--;
+    }
+}
+
+extern __shared__ float4 rt_lds[];
+
+// Stages nodes, leaf references, spheres and triangle intersection records into LDS and
+// returns views into it (layout = ldsSceneBytes()).
+__device__ __forceinline__ SceneView stageScene(const DevScene& sc) {
+    auto al = [](int x) { return (x + 15) & ~15; };
+    char* base = reinterpret_cast<char*>(rt_lds);
+    const int nb = al(sc.n_nodes * 32), rb = al(sc.n_prim_refs * 4), sb = al(sc.n_spheres * 16), tb = al(sc.n_tris * 48);
+    float4* nodes = reinterpret_cast<float4*>(base);
+    uint32_t* refs = reinterpret_cast<uint32_t*>(base + nb);
+    float4* spheres = reinterpret_cast<float4*>(base + nb + rb);
+    float4* tris = reinterpret_cast<float4*>(base + nb + rb + sb);
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int i = tid; i < sc.n_nodes * 2; i += nt) nodes[i] = sc.nodes[i];
+    for (int i = tid; i < sc.n_prim_refs; i += nt) refs[i] = sc.prim_refs[i];
+    for (int i = tid; i < sc.n_spheres; i += nt) spheres[i] = sc.spheres[i];
+    for (int i = tid; i < sc.n_tris * 3; i += nt) tris[i] = sc.tri_isect[i];
+    (void)tb;
+    __syncthreads();
+    return SceneView{nodes, refs, spheres, tris};
+}
+
+// Pixel loops of RaytracerNormal::Run (R/src/Core/Raytracer.cpp:76-93) for the tiles this
+// rank owns.  Wave w of the launch takes local tiles w, w + nWaves, ... (or pulls them from
+// `queue` when it is non-null); lane l of a tile is pixel (l & 7, l >> 3) inside it.
+template <bool LDS, bool COUNT>
+__global__ void __launch_bounds__(256) renderKernel(RenderArgs a) {
+    const DevScene& sc = a.sc;
+    SceneView sv;
+    if (LDS) {
+        sv = stageScene(sc);
+    } else {
+        sv = SceneView{sc.nodes, sc.prim_refs, sc.spheres, sc.tri_isect};
+    }
+    const int lane = threadIdx.x & 63;
+    const int wavesPerBlock = blockDim.x >> 6;
+    const int wave = blockIdx.x * wavesPerBlock + (threadIdx.x >> 6);
+    const int nWaves = gridDim.x * wavesPerBlock;
+    Stats st;
+    if (COUNT)
+        for (int i = 0; i < 13; i++) st.v[i] = 0;
+
+    int tile = wave;
+    if (a.queue) {
+        unsigned int t = 0;
+        if (lane == 0) t = atomicAdd(a.queue, 1u);
+        tile = (int)__builtin_amdgcn_readfirstlane(t);
+    }
+    while (tile < a.n_local_tiles) {
+        const int ty = tile / a.tiles_per_row_local;
+        const int k = tile - ty * a.tiles_per_row_local;
+        int base = (a.rank - ty) % a.world;
+        if (base < 0) base += a.world;
+        const int tx = base + k * a.world;
+        const int x = tx * kTile + (lane & 7), y = ty * kTile + (lane >> 3);
+        if (tx < a.tiles_x && x < a.width && y < a.height) {
+            float4 acc = a.accum[(size_t)tile * 64 + lane];
+            V3 sum{acc.x, acc.y, acc.z};
+            for (int s = a.first_sample; s < a.first_sample + a.n_samples; ++s) {
+                Rng rng;
+                rng.init((uint32_t)x, (uint32_t)y, s);
+                if (COUNT) st.v[C_SAMPLES]++;
+                // u is drawn before v (R/src/Core/Raytracer.cpp:86-87)
+                float u = ((float)x + rng.next()) / (float)(a.width - 1);
+                float v = ((float)y + rng.next()) / (float)(a.height - 1);
+                Ray r = cameraRay(sc, u, v, rng);
+                V3 c = rayColor<COUNT>(sc, sv, r, a.max_depth, rng, &st);
+                sum = sum + c;
+            }
+            a.accum[(size_t)tile * 64 + lane] = make_float4(sum.x, sum.y, sum.z, (float)(a.first_sample + a.n_samples));
+        }
+        if (a.queue) {
+            unsigned int t = 0;
+            if (lane == 0) t = atomicAdd(a.queue, 1u);
+            tile = (int)__builtin_amdgcn_readfirstlane(t);
+        } else {
+            tile += nWaves;
+        }
+    }
+    if (COUNT) {
+        for (int i = 0; i < 13; i++) {
+            unsigned long long v = st.v[i];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+            if (lane == 0 && v) atomicAdd(&a.counters[i], v);
+        }
+    }
+}
+
+// Closest hit + hit record of arbitrary rays (test hook behind rt_trace).
+__global__ void __launch_bounds__(256) traceKernel(DevScene sc, int n, const float* rays, int* kind, int* id, float* t,
+                                                   float* normal, int* front, float* uv) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    SceneView sv{sc.nodes, sc.prim_refs, sc.spheres, sc.tri_isect};
+    Ray r;
+    r.o = {rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]};
+    r.d = {rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]};
+    Hit h = traverse<false>(sv, sc.n_nodes, r, nullptr);
+    if (h.ref == kNoHit) {
+        kind[i] = -1;
+        id[i] = -1;
+        t[i] = __builtin_inff();
+        normal[3 * i] = normal[3 * i + 1] = normal[3 * i + 2] = 0.0f;
+        front[i] = 0;
+        uv[2 * i] = uv[2 * i + 1] = 0.0f;
+        return;
+    }
+    Surface s = surfaceAt(sc, sv, r, h);
+    kind[i] = (h.ref & kRefTri) ? 1 : 0;
+    id[i] = (int)(h.ref & kRefId);
+    t[i] = h.t;
+    normal[3 * i] = s.n.x;
+    normal[3 * i + 1] = s.n.y;
+    normal[3 * i + 2] = s.n.z;
+    front[i] = s.front ? 1 : 0;
+    uv[2 * i] = s.u;
+    uv[2 * i + 1] = s.v;
+}
+
+// One scatter event with injected geometry (test hook).
+__global__ void scatterKernel(DevScene sc, int n, const int* mat, const float* rayIn, const float* p, const float* nrm,
+                              const int* front, const float* uv, const unsigned int* key4, float* atten, float* rayOut,
+                              int* alive, unsigned int* counterOut) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Ray in;
+    in.o = {rayIn[6 * i], rayIn[6 * i + 1], rayIn[6 * i + 2]};
+    in.d = {rayIn[6 * i + 3], rayIn[6 * i + 4], rayIn[6 * i + 5]};
+    Surface s;
+    s.p = {p[3 * i], p[3 * i + 1], p[3 * i + 2]};
+    s.n = {nrm[3 * i], nrm[3 * i + 1], nrm[3 * i + 2]};
+    s.front = front[i] != 0;
+    s.u = uv[2 * i];
+    s.v = uv[2 * i + 1];
+    s.mat = mat[i];
+    Rng rng;
+    rng.init(key4[4 * i], key4[4 * i + 1], (int)key4[4 * i + 2]);
+    rng.counter = key4[4 * i + 3];
+    Ray out;
+    out.o = {0, 0, 0};
+    out.d = {0, 0, 0};
+    V3 att{0, 0, 0}, emit;
+    bool ok = scatter<false>(sc, in, s, rng, out, att, emit, nullptr);
+    atten[3 * i] = att.x;
+    atten[3 * i + 1] = att.y;
+    atten[3 * i + 2] = att.z;
+    rayOut[6 * i] = out.o.x;
+    rayOut[6 * i + 1] = out.o.y;
+    rayOut[6 * i + 2] = out.o.z;
+    rayOut[6 * i + 3] = out.d.x;
+    rayOut[6 * i + 4] = out.d.y;
+    rayOut[6 * i + 5] = out.d.z;
+    alive[i] = ok ? 1 : 0;
+    counterOut[i] = rng.counter;
+}
+
+// Tiled rank payloads -> row-major image.  `payloads` holds `world` accumulation buffers of
+// `stride4` float4 each (world == 1 with rank r: only that rank's pixels are filled).
+// mode 0: RGBA32F sums with alpha 1; mode 1: writeColor bytes (R/src/Core/Raytracer.cpp:22-44).
+__global__ void __launch_bounds__(256) resolveKernel(const float4* payloads, size_t stride4, int width, int height,
+                                                     int tiles_per_row_local, int world, int only_rank, int mode,
+                                                     int samples_per_pixel, float4* out32, uint32_t* out8) {
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (x >= width || y >= height) return;
+    const int tx = x >> 3, ty = y >> 3;
+    const int owner = (tx + ty) % world;
+    int base = (owner - ty) % world;
+    if (base < 0) base += world;
+    const int k = (tx - base) / world;
+    const int lane = (x & 7) | ((y & 7) << 3);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (only_rank < 0)
+        v = payloads[(size_t)owner * stride4 + ((size_t)(ty * tiles_per_row_local + k)) * 64 + lane];
+    else if (owner == only_rank)
+        v = payloads[((size_t)(ty * tiles_per_row_local + k)) * 64 + lane];
+    const size_t o = (size_t)y * width + x;
+    if (mode == 0) {
+        out32[o] = make_float4(v.x, v.y, v.z, 1.0f);
+    } else {
+        const float scale = 1.0f / samples_per_pixel;
+        float r = sqrtf(scale * v.x), g = sqrtf(scale * v.y), b = sqrtf(scale * v.z);
+        auto cl = [](float q) { return q < 0.0f ? 0.0f : (q > 0.999f ? 0.999f : q); };
+        uint32_t ri = (uint32_t)(uint8_t)(int)(256 * cl(r)), gi = (uint32_t)(uint8_t)(int)(256 * cl(g)),
+                 bi = (uint32_t)(uint8_t)(int)(256 * cl(b));
+        out8[o] = ri | (gi << 8) | (bi << 16) | (255u << 24);
+    }
+}
+
+// ------------------------------------------------------------------ launch wrappers
+hipError_t launchRender(const RenderArgs& a, bool lds, bool count, int blocks, int threads, hipStream_t stream) {
+    size_t shmem = lds ? (size_t)a.lds_bytes : 0;
+    if (lds && !count) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(renderKernel<true, false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        renderKernel<true, false><<<blocks, threads, shmem, stream>>>(a);
+    } else if (lds && count) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(renderKernel<true, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        renderKernel<true, true><<<blocks, threads, shmem, stream>>>(a);
+    } else if (!count) {
+        renderKernel<false, false><<<blocks, threads, 0, stream>>>(a);
+    } else {
+        renderKernel<false, true><<<blocks, threads, 0, stream>>>(a);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launchTrace(const DevScene& sc, int n, const float* rays, int* kind, int* id, float* t, float* normal,
+                       int* front, float* uv, hipStream_t stream) {
+    traceKernel<<<(n + 255) / 256, 256, 0, stream>>>(sc, n, rays, kind, id, t, normal, front, uv);
+    return hipGetLastError();
+}
+
+hipError_t launchScatter(const DevScene& sc, int n, const int* mat, const float* rayIn, const float* p, const float* nrm,
+                         const int* front, const float* uv, const unsigned int* key4, float* atten, float* rayOut,
+                         int* alive, unsigned int* counterOut, hipStream_t stream) {
+    scatterKernel<<<(n + 63) / 64, 64, 0, stream>>>(sc, n, mat, rayIn, p, nrm, front, uv, key4, atten, rayOut, alive,
+                                                   counterOut);
+    return hipGetLastError();
+}
+
+hipError_t launchResolve(const float4* payloads, size_t stride4, int width, int height, int tiles_per_row_local,
+                         int world, int only_rank, int mode, int spp, float4* out32, uint32_t* out8, hipStream_t stream) {
+    dim3 grid((width + 31) / 32, (height + 7) / 8);
+    resolveKernel<<<grid, 256, 0, stream>>>(payloads, stride4, width, height, tiles_per_row_local, world, only_rank,
+                                            mode, spp, out32, out8);
+    return hipGetLastError();
+}
+
+}  // namespace rt
