@@ -1,0 +1,196 @@
+"""Benchmark of the path-tracing hot path: Msamples/s on the Book-1 cover scene, 1920x1080,
+max depth 50, one frame of 64 samples per pixel per GPU per step.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+One step = clear the accumulation buffer + one render launch of `spp` samples of every owned
+pixel (+ for N > 1 one all-gather of the rank payloads over RCCL and the device resolve into the
+row-major RGBA32F frame).  N GPUs shard the 8x8-pixel tiles of the same 1080p frame and each
+renders 64*N samples per pixel of its tiles, so per-GPU work is fixed ("weak" scaling) and the
+gathered frame is a 64*N-spp image.  The scene lives in device memory before timing starts; the
+frame stays in device memory (the PCIe-inclusive figure is in DESIGN.md).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+from __graft_entry__ import load_oracle, load_package  # noqa: E402
+
+W, H, SPP, MAX_DEPTH = 1920, 1080, 64, 50
+PEAK_FP32_TFLOPS = 157.3  # MI355X peak FP32 vector rate (MI355X_MICROARCH.md, chip-level parameters)
+
+# Algorithmic flop costs (add/sub/mul = 1, fma = 2, div/rcp/sqrt = 1, compare/select/int = 0),
+# following the reference's arithmetic: slab test 3 x (1 rcp + 2 sub + 2 mul); sphere test to the
+# discriminant 23; triangle test 51; per accepted closest hit: one root 3 + hit record 17
+# (triangle: 40); scatter by kind; camera ray + pixel jitter 34; accumulate 3 per sample.
+COST = {"node_tests": 15, "sphere_tests": 23, "tri_tests": 51, "hits": 20, "scatter_lambertian": 35,
+        "scatter_metal": 55, "scatter_dielectric": 60, "scatter_pbr": 60, "samples": 37}
+
+
+def flops_from_counters(c):
+    return float(sum(c[k] * v for k, v in COST.items()))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--spp", type=int, default=SPP, help="samples per pixel per GPU per step")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device; the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    rt = load_package()
+    from rtiow_amd import scenes, tiling
+
+    scene = rt.Scene()
+    scenes.cover_scene(scene, W, H, wrap_bvh=True)
+    ctx = rt.Context(local_rank)
+    # One side stream carries everything: torch's fills and collectives are ordered against the
+    # render and resolve kernels on it without host synchronisation.
+    stream = torch.cuda.Stream(dev)
+    torch.cuda.set_stream(stream)
+    ctx.set_stream(stream.cuda_stream)
+    ctx.upload_scene(scene)
+
+    n4 = tiling.payload_float4s(W, H, world)
+    payload = torch.zeros(n4, 4, dtype=torch.float32, device=dev)
+    gathered = torch.zeros(world, n4, 4, dtype=torch.float32, device=dev) if world > 1 else None
+    frame = torch.zeros(H, W, 4, dtype=torch.float32, device=dev) if world > 1 else None
+    ctx.set_target(W, H, rank, world, external_ptr=payload.data_ptr())
+    spp_step = args.spp * world  # per-GPU work fixed: 1/world of the tiles, world x the samples
+    kernel_ms = []
+
+    def step(record):
+        payload.zero_()
+        ctx.render(0, spp_step, MAX_DEPTH)
+        if record:
+            kernel_ms.append(ctx.last_render_ms())
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, payload)
+            ctx.resolve_gathered(gathered.data_ptr(), world, frame.data_ptr())
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step(False)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(False)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # Kernel duration by HIP events on the launch stream, in separate untimed steps (reading an
+    # event blocks the host, which must not sit inside the timed region).
+    for _ in range(3):
+        step(True)
+    fence()
+    avg_kernel_ms = float(np.mean(kernel_ms))
+
+    samples_per_step = W * H * args.spp * world  # whole job: every pixel, spp*world samples
+    value = samples_per_step * args.steps / elapsed / 1e6
+
+    out = {
+        "metric": "Msamples/s (1080p, 50 bounces)",
+        "value": round(value, 2),
+        "unit": "Msamples/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"Book-1 cover scene (488 spheres, BVH(world)), {W}x{H}, {args.spp} spp per GPU per step "
+                        f"({spp_step} spp frame), max depth 50, progressive accumulation",
+            "samples_per_step": samples_per_step,
+            "parallelism": f"tiles8x8 sharded over {world} rank(s)" + (", all-gather (RCCL)" if world > 1 else ""),
+            "ms_per_64spp_frame": round(1e3 * elapsed / args.steps * 64.0 / spp_step, 4),
+        },
+    }
+
+    if rank == 0:
+        # Algorithmic flops per launch from the kernel's own path statistics (a counting launch
+        # over the same pixels and samples, untimed), priced with COST.
+        counters = ctx.count(0, min(spp_step, 8), MAX_DEPTH)
+        flops_per_sample = flops_from_counters(counters) / counters["samples"]
+        own_samples = W * H * spp_step / world
+        achieved = flops_per_sample * own_samples / (avg_kernel_ms * 1e-3) / 1e12
+        out["roofline"] = {
+            "bound": "valu_fp32",
+            "achieved": round(achieved, 3),
+            "peak": PEAK_FP32_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": round(achieved / PEAK_FP32_TFLOPS, 4),
+            "traffic": None,
+            "kernel": "renderKernel",
+            "kernel_ms": round(avg_kernel_ms, 4),
+            "flops_per_sample": round(flops_per_sample, 1),
+            "rays_per_sample": round(counters["rays"] / counters["samples"], 3),
+            "node_tests_per_ray": round(counters["node_tests"] / counters["rays"], 2),
+            "sphere_tests_per_ray": round(counters["sphere_tests"] / counters["rays"], 2),
+        }
+    ctx.close()
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        orc = load_oracle()
+        threads = max(1, min(16, int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))))
+        cpu_spp = 4
+        o = orc.OracleScene()
+        scenes.cover_scene(o, W, H, wrap_bvh=True)
+        t0 = time.perf_counter()
+        o.render(W, H, 0, cpu_spp, MAX_DEPTH, rng_mode=1, order=1, threads=threads)
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {
+            "value": round(W * H * cpu_spp / dt / 1e6, 3),
+            "unit": "Msamples/s",
+            "cores": threads,
+            "kind": "port",
+            "sample": f"same scene and camera, {W}x{H} at {cpu_spp} spp ({W * H * cpu_spp / 1e6:.1f} M samples), "
+                      f"scalar CPU oracle with BVH, {threads} threads, {dt:.1f} s wall",
+        }
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

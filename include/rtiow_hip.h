@@ -143,6 +143,11 @@ int rt_device_count(void);
 int rt_create(int device, rt_context** out);
 void rt_destroy(rt_context* ctx);
 
+/* Makes the context issue all later work on `hip_stream` (a hipStream_t the caller owns, on the
+ * context's device) instead of its own stream, so that a caller's collectives and these kernels
+ * are ordered on one stream without host synchronisation.  NULL restores the context's stream. */
+int rt_set_stream(rt_context* ctx, void* hip_stream);
+
 /* Copies the flattened scene, camera and background to the device (replaces what
  * `Raytracer`'s constructor captures from Scene&, Raytracer.h:27-31). */
 int rt_upload_scene(rt_context* ctx, rt_scene* s);

@@ -72,6 +72,7 @@ SYMBOLS = {
     "rt_device_count": (_I, []),
     "rt_create": (_I, [_I, C.POINTER(_VP)]),
     "rt_destroy": (None, [_VP]),
+    "rt_set_stream": (_I, [_VP, _VP]),
     "rt_upload_scene": (_I, [_VP, _VP]),
     "rt_set_target": (_I, [_VP, _I, _I, _I, _I]),
     "rt_set_target_external": (_I, [_VP, _I, _I, _I, _I, _VP]),
@@ -254,6 +255,9 @@ class Context:
 
     def __del__(self):
         self.close()
+
+    def set_stream(self, hip_stream):
+        _check(lib.rt_set_stream(self.h, C.c_void_p(hip_stream)))
 
     def upload_scene(self, scene):
         _check(lib.rt_upload_scene(self.h, scene.h))

@@ -31,7 +31,8 @@ struct rt_scene {
 
 struct rt_context {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;      // the stream in use
+    hipStream_t own_stream = nullptr;  // created by rt_create()
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
     rt::DevScene dsc{};
@@ -312,7 +313,8 @@ int rt_create(int device, rt_context** out) {
     ctx->device = device;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->n_cus = prop.multiProcessorCount;
-    hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    hipError_t e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
+    ctx->stream = ctx->own_stream;
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
     if (e == hipSuccess) e = hipMalloc((void**)&ctx->queue, 256);
@@ -335,8 +337,16 @@ void rt_destroy(rt_context* ctx) {
     if (ctx->counters) (void)hipFree(ctx->counters);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
-    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
+}
+
+int rt_set_stream(rt_context* ctx, void* hip_stream) {
+    if (!ctx) return fail(RT_ERR_INVALID, "null context");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    return RT_OK;
 }
 
 int rt_upload_scene(rt_context* ctx, rt_scene* s) {

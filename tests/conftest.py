@@ -1,0 +1,60 @@
+"""Shared fixtures.  GPU tests are marked `gpu`; everything else runs without a device."""
+import importlib.util
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG_DIR = os.path.join(ROOT, "raytracing-in-one-weekend_amd")
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+def load_package():
+    """Imports the product package (its directory name is not a Python identifier)."""
+    if "rtiow_amd" in sys.modules:
+        return sys.modules["rtiow_amd"]
+    spec = importlib.util.spec_from_file_location(
+        "rtiow_amd", os.path.join(PKG_DIR, "__init__.py"), submodule_search_locations=[PKG_DIR])
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["rtiow_amd"] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.fixture(scope="session")
+def rt():
+    return load_package()
+
+
+@pytest.fixture(scope="session")
+def scenes(rt):
+    import importlib
+    return importlib.import_module("rtiow_amd.scenes")
+
+
+@pytest.fixture(scope="session")
+def tiling(rt):
+    import importlib
+    return importlib.import_module("rtiow_amd.tiling")
+
+
+@pytest.fixture(scope="session")
+def orc():
+    import _oracle
+    _oracle.lib()
+    return _oracle
+
+
+@pytest.fixture(scope="session")
+def gpu_ctx(rt):
+    """One context on device 0 shared by the GPU tests (a box allows few GPU processes)."""
+    if rt.device_count() < 1:
+        pytest.fail("GPU test selected but no HIP device is visible; the product path has no CPU fallback")
+    ctx = rt.Context(0)
+    yield ctx
+    ctx.close()

@@ -1,0 +1,57 @@
+"""The C-ABI library loads without a GPU and exports every symbol the header declares."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "rtiow_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = set(re.findall(r"\b(rt_[a-z0-9_]+)\s*\(", text))
+    names.discard("rt_pass_callback")
+    return sorted(names)
+
+
+def test_header_symbols_are_exported(rt):
+    names = declared_symbols()
+    assert len(names) >= 35
+    for n in names:
+        assert hasattr(rt.lib, n), f"{n} declared in include/rtiow_hip.h but not exported"
+    # the binding table covers exactly the header
+    assert sorted(rt.SYMBOLS) == names
+
+
+def test_version_and_status_codes(rt):
+    assert b"gfx950" in rt.lib.rt_version()
+    assert rt.lib.rt_accum_bytes(1920, 1080, 1) == 240 * 135 * 64 * 16
+    assert rt.lib.rt_accum_bytes(1920, 1080, 8) == 30 * 135 * 64 * 16
+    assert rt.lib.rt_accum_bytes(10, 10, 1) == 2 * 2 * 64 * 16
+    assert rt.lib.rt_accum_bytes(0, 10, 1) == 0
+
+
+def test_device_entry_points_fail_loudly_without_a_gpu(rt):
+    """No CPU fallback: without a device, context creation reports RT_ERR_NO_DEVICE."""
+    if rt.device_count() > 0:
+        pytest.skip("a HIP device is present")
+    h = ctypes.c_void_p()
+    rc = rt.lib.rt_create(0, ctypes.byref(h))
+    assert rc == rt.RT_ERR_NO_DEVICE
+    assert b"no CPU path" in rt.lib.rt_last_error()
+    with pytest.raises(rt.RtError):
+        rt.Context(0)
+    # null-handle calls are rejected, not crashed on
+    assert rt.lib.rt_render(None, 0, 1, 50) < 0
+    assert rt.lib.rt_sync(None) < 0
+    assert rt.lib.rt_upload_scene(None, None) < 0
+
+
+def test_product_library_does_not_link_the_oracle(rt):
+    import subprocess
+    out = subprocess.run(["ldd", rt.LIB_PATH], capture_output=True, text=True).stdout
+    assert "oracle" not in out
+    syms = subprocess.run(["nm", "-D", "--defined-only", rt.LIB_PATH], capture_output=True, text=True).stdout
+    assert "orc_" not in syms

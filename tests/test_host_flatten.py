@@ -1,0 +1,200 @@
+"""The product's host code (scene build, reference-order BVH, flatten step) against the oracle.
+
+No GPU needed: these compare the packed arrays the library would upload with the oracle's
+pointer-tree walk, bit for bit.
+"""
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+G = os.path.join(HERE, "golden")
+NOBOX = 1 << 30
+LAST, TRI = 1 << 31, 1 << 30
+
+
+def flat_views(flat):
+    nodes = flat["nodes"]
+    has_box = (nodes[:, 3] & NOBOX) == 0
+    skip = (nodes[:, 3] & (NOBOX - 1)).astype(np.int64)
+    first = nodes[:, 7].view(np.int32)
+    boxes = np.concatenate([nodes[:, 0:3], nodes[:, 4:7]], axis=1)
+    return has_box, skip, first, boxes
+
+
+def check_structure(flat, orc_boxes, orc_desc, orc_prims):
+    """Entries with a box test, in order, are the oracle's box-tested nodes in visit order; a
+    miss skips exactly the node's subtree; leaf references are the oracle's primitive visit order."""
+    has_box, skip, first, boxes = flat_views(flat)
+    n = len(skip)
+    assert np.array_equal(boxes[has_box], orc_boxes.view(np.uint32))
+    refs = flat["prim_refs"]
+    kinds = ((refs & TRI) != 0).astype(np.int32)
+    ids = (refs & (TRI - 1)).astype(np.int32)
+    assert np.array_equal(np.stack([kinds, ids], axis=1), orc_prims)
+    # skip links: entry e's subtree holds desc[k] box-tested entries
+    box_idx = np.nonzero(has_box)[0]
+    assert len(box_idx) == len(orc_desc)
+    for k, e in enumerate(box_idx):
+        inside = np.count_nonzero(has_box[e + 1:skip[e]])
+        assert inside == orc_desc[k]
+        assert e < skip[e] <= n
+    # entries without a box never skip anything
+    for e in np.nonzero(~has_box)[0]:
+        assert skip[e] == e + 1 and first[e] >= 0
+    # every leaf run is terminated, runs are visited in array order, and all references are used
+    pos = 0
+    for e in range(n):
+        if first[e] >= 0:
+            assert first[e] == pos
+            while not (refs[pos] & LAST):
+                pos += 1
+            pos += 1
+    assert pos == len(refs)
+
+
+def build_both(rt, orc, builder):
+    a, b = rt.Scene(), orc.OracleScene()
+    builder(a)
+    builder(b)
+    return a, b
+
+
+def compare_scene_arrays(flat, od):
+    assert np.array_equal(flat["spheres"].view(np.uint32), od["spheres"].view(np.uint32))
+    assert np.array_equal(flat["sphere_mat"], od["sphere_mat"])
+    assert np.array_equal(flat["mat_kind"], od["mat_kind"])
+    assert np.array_equal(flat["mat_rgbp"].view(np.uint32), od["mat_rgbp"].view(np.uint32))
+    if od["tris"].shape[0]:
+        assert np.array_equal(flat["tri_pos"].view(np.uint32), od["tris"][:, 0:9].view(np.uint32))
+        assert np.array_equal(flat["tri_normal"].view(np.uint32), od["tris"][:, 9:18].view(np.uint32))
+        assert np.array_equal(flat["tri_uv"].view(np.uint32), od["tris"][:, 18:24].view(np.uint32))
+        assert np.array_equal(flat["tri_mat"], od["tri_mat"])
+
+
+def test_rng_stream(rt, orc):
+    a, b = rt.Scene(), orc.OracleScene()
+    assert np.array_equal(a.rng_floats(1000).view(np.uint32), b.rng_floats(1000).view(np.uint32))
+
+
+@pytest.mark.parametrize("wrap", [False, True])
+def test_cover_scene_flatten(rt, orc, scenes, wrap):
+    a, b = build_both(rt, orc, lambda s: scenes.cover_scene(s, 1920, 1080, wrap_bvh=wrap))
+    flat = a.get_flat()
+    compare_scene_arrays(flat, b.dump())
+    check_structure(flat, *b.dump_tree())
+    assert np.array_equal(a.get_camera().view(np.uint32), b.get_camera().view(np.uint32))
+    info = flat["info"]
+    assert info.n_spheres == 488 and info.n_prim_refs == 488 and info.fits_lds == 1
+    if wrap:
+        assert info.n_nodes == 511 and info.max_leaf == 2
+        g = np.load(os.path.join(G, "cover_scene.npz"))
+        has_box, _, _, boxes = flat_views(flat)
+        assert np.array_equal(boxes[has_box], g["boxes"])
+    else:
+        assert info.n_nodes == 1 and info.max_leaf == 488
+    # the generator continues identically after the build on both sides
+    assert np.array_equal(a.rng_floats(16).view(np.uint32), b.rng_floats(16).view(np.uint32))
+
+
+def test_cornell_and_gltf_mesh_flatten(rt, orc, scenes):
+    path = os.path.join(G, "brass_vase", "brass_vase_04_4k.gltf")
+    mesh = scenes.load_gltf_mesh(path)
+    tex = {"diffuse": scenes.noise_texture(16, 1), "roughness": scenes.noise_texture(16, 2), "normal": None}
+    a, b = build_both(rt, orc, lambda s: scenes.cornell_mesh_scene(s, 640, 360, mesh, tex))
+    flat = a.get_flat()
+    compare_scene_arrays(flat, b.dump())
+    check_structure(flat, *b.dump_tree())
+    assert flat["info"].n_triangles == 12 + 2760
+    # the library's own glTF reader gives the same mesh as the numpy reader
+    c = rt.Scene()
+    c.cornell_box()
+    td, tr = c.add_texture(tex["diffuse"]), c.add_texture(tex["roughness"])
+    c.add_mesh_gltf(scenes.VASE_MODEL, path, c.add_pbr(td, tr, -1), max_depth=10)
+    flat_c = c.get_flat()
+    for k in ("nodes", "prim_refs", "tri_pos", "tri_normal", "tri_uv", "tri_mat"):
+        assert np.array_equal(flat_c[k], flat[k]), k
+
+
+@pytest.mark.parametrize("max_depth", [0, 1, 3, -1])
+def test_mesh_bvh_depth_limits(rt, orc, scenes, max_depth):
+    mesh = scenes.lathe_mesh(10, 7, seed=3)
+    tex = {"diffuse": scenes.noise_texture(8, 5), "roughness": None, "normal": None}
+    a, b = build_both(rt, orc, lambda s: scenes.cornell_mesh_scene(s, 64, 64, mesh, tex, max_depth=max_depth))
+    flat = a.get_flat()
+    compare_scene_arrays(flat, b.dump())
+    check_structure(flat, *b.dump_tree())
+
+
+def test_mixed_world_wrapped_in_bvh(rt, orc, scenes):
+    """Spheres, loose triangles and a mesh under one top-level BVH: leaves that are composites."""
+    mesh = scenes.lathe_mesh(6, 4, seed=9)
+    r = np.random.RandomState(5)
+
+    def build(s):
+        m = [s.add_material(0, (0.5, 0.4, 0.3)), s.add_material(1, (0.9, 0.8, 0.7), 0.2), s.add_material(2, (0, 0, 0), 1.5)]
+        rr = np.random.RandomState(5)
+        for i in range(23):
+            c = (rr.rand(3) * 400 + 50).astype(np.float32)
+            s.add_sphere(c, float(np.float32(5 + 20 * rr.rand())), m[i % 3])
+        for i in range(7):
+            p = (rr.rand(9) * 500).astype(np.float32)
+            s.add_triangle(p, m[i % 2])
+        td = s.add_texture(scenes.noise_texture(8, 1))
+        s.add_mesh(scenes.VASE_MODEL, mesh["positions"], mesh["indices"], s.add_pbr(td, -1, -1),
+                   normals=mesh["normals"], uvs=mesh["uvs"], max_depth=2)
+        s.add_sphere((10.0, 10.0, 10.0), 3.0, m[0])
+        s.wrap_bvh()
+
+    del r
+    a, b = build_both(rt, orc, build)
+    flat = a.get_flat()
+    compare_scene_arrays(flat, b.dump())
+    check_structure(flat, *b.dump_tree())
+
+
+def test_duplicate_box_minima_sort_like_the_oracle(rt, orc):
+    """Every small cover-scene sphere has the same minimum y, so an axis-1 split is decided by
+    std::sort's handling of ties; exercise that with many equal keys."""
+    def build(s):
+        m = s.add_material(0, (0.5, 0.5, 0.5))
+        rr = np.random.RandomState(11)
+        for i in range(200):
+            x, z = rr.rand(2) * 20
+            s.add_sphere((float(np.float32(x)), 0.2, float(np.float32(z))), 0.2, m)
+        s.wrap_bvh()
+
+    a, b = build_both(rt, orc, build)
+    check_structure(a.get_flat(), *b.dump_tree())
+
+
+def test_box_helper_emits_twelve_triangles(rt):
+    s = rt.Scene()
+    m = s.add_material(0, (0.73, 0.73, 0.73))
+    first = s.add_box((0, 0, 0), (165, 330, 165), m, rt.translate_scale((265, 0, 295), (1, 1, 1)))
+    flat = s.get_flat()
+    assert first == 0 and flat["info"].n_triangles == 12 and flat["info"].n_nodes == 1
+    pos = flat["tri_pos"].reshape(12, 3, 3)
+    assert pos[..., 0].min() == 265 and pos[..., 0].max() == 430
+    assert pos[..., 1].min() == 0 and pos[..., 1].max() == 330
+    assert (flat["tri_normal"] == 0).all()
+    # first side of the reference's Box: (p0), (p0.x,p0.y,p1.z), (p0.x,p1.y,p0.z)
+    assert pos[0].tolist() == [[265, 0, 295], [265, 0, 460], [265, 330, 295]]
+
+
+def test_error_paths(rt):
+    s = rt.Scene()
+    with pytest.raises(rt.RtError):
+        s.add_sphere((0, 0, 0), 1.0, 0)          # no such material
+    with pytest.raises(rt.RtError):
+        s.wrap_bvh()                              # empty world
+    with pytest.raises(rt.RtError):
+        s.add_pbr(0)                              # no such texture
+    m = s.add_material(0, (1, 1, 1))
+    with pytest.raises(rt.RtError):
+        s.add_mesh(rt.IDENTITY, np.zeros((3, 3), np.float32), np.array([[0, 1, 7]], np.uint32), m)
+    with pytest.raises(rt.RtError):
+        s.add_mesh_gltf(rt.IDENTITY, "/nonexistent/file.gltf", m)
+    assert rt.lib.rt_scene_flatten(None, None) < 0
+    assert b"null" in rt.lib.rt_last_error()
