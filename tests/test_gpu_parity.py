@@ -37,16 +37,31 @@ def rays_cornell(n, seed):
     return golden_rays(n, seed, target=(278, 250, 278), spread=400.0, origin_box=((100, 100, -800), (450, 450, -100)))
 
 
-def assert_trace_equal(ctx, oscene, rays):
+def assert_trace_equal(ctx, oscene, rays, smooth_tri=None):
+    """Hit kind, id, t and normal must be identical everywhere.  Two HitRecord fields are left
+    unwritten by the reference and are compared only where it writes them: (u, v) is written by
+    Triangle::Hit only (Sphere::Hit leaves whatever an earlier candidate stored), and frontFace
+    is not written for triangles with vertex normals (R/src/Core/Hittable.h:93-96)."""
     k, p, t, n, f, uv = ctx.trace(rays)
     ok, op, ot, on, of, ouv = oscene.trace(rays)
     assert np.array_equal(k, ok)
     assert np.array_equal(p, op)
     assert np.array_equal(bits(t), bits(ot))
     assert np.array_equal(bits(n), bits(on))
-    assert np.array_equal(f, of)
-    assert np.array_equal(bits(uv), bits(ouv))
+    tri = k == 1
+    front_defined = k == 0
+    if smooth_tri is not None:
+        front_defined |= tri & ~smooth_tri[np.where(tri, p, 0)]
+    else:
+        front_defined |= tri
+    assert np.array_equal(f[front_defined], of[front_defined])
+    assert np.array_equal(bits(uv)[tri], bits(ouv)[tri])
     return k
+
+
+def smooth_flags(scene):
+    """True for triangles whose first vertex normal is non-zero (interpolated shading normal)."""
+    return (scene.get_flat()["tri_normal"][:, 0:3] != 0).any(axis=1)
 
 
 @pytest.mark.parametrize("wrap", [True, False])
@@ -93,7 +108,7 @@ def test_trace_cornell_vase(rt, orc, scenes, gpu_ctx):
     tex = {"diffuse": scenes.noise_texture(64, 1), "roughness": scenes.noise_texture(64, 2), "normal": None}
     a, b = both(rt, orc, lambda s: scenes.cornell_mesh_scene(s, 640, 360, mesh, tex))
     gpu_ctx.upload_scene(a)
-    k = assert_trace_equal(gpu_ctx, b, rays_cornell(50000, 21))
+    k = assert_trace_equal(gpu_ctx, b, rays_cornell(50000, 21), smooth_flags(a))
     assert (k == 1).mean() > 0.9
     g = np.load(os.path.join(G, "vase_scene.npz"))
     k, p, t, n, f, uv = gpu_ctx.trace(rays_cornell(4096, 99))
@@ -120,7 +135,7 @@ def test_trace_mixed_world(rt, orc, scenes, gpu_ctx, max_depth):
 
     a, b = both(rt, orc, build)
     gpu_ctx.upload_scene(a)
-    assert_trace_equal(gpu_ctx, b, rays_cornell(30000, 5))
+    assert_trace_equal(gpu_ctx, b, rays_cornell(30000, 5), smooth_flags(a))
 
 
 def test_scatter_table(rt, orc, scenes, gpu_ctx):
