@@ -220,6 +220,11 @@ typedef struct rt_counters {
 } rt_counters;
 int rt_count(rt_context* ctx, int first_sample, int n_samples, int max_depth, rt_counters* out);
 
+/* Diagnostics of the wavefront scheduler, filled by the last rt_count(): for each lane operation
+ * (box test, primitive test, shade, new path, new pixel, and box steps inside a burst) the number
+ * of wave-level executions and the number of lanes that took part.  No reference counterpart. */
+int rt_sched_stats(rt_context* ctx, uint64_t* out12);
+
 /* Milliseconds the last rt_render() kernel took on the device (HIP events on the context's
  * stream).  Blocks until that kernel has finished. */
 int rt_last_render_ms(rt_context* ctx, float* ms);

@@ -88,6 +88,7 @@ SYMBOLS = {
     "rt_trace": (_I, [_VP, _I] + [_VP] * 7),
     "rt_scatter_test": (_I, [_VP, _I] + [_VP] * 11),
     "rt_count": (_I, [_VP, _I, _I, _I, C.POINTER(Counters)]),
+    "rt_sched_stats": (_I, [_VP, _VP]),
     "rt_last_render_ms": (_I, [_VP, C.POINTER(C.c_float)]),
     "rt_stream": (_VP, [_VP]),
 }
@@ -328,6 +329,12 @@ class Context:
         c = Counters()
         _check(lib.rt_count(self.h, first_sample, n_samples, max_depth, C.byref(c)))
         return c.as_dict()
+
+    def sched_stats(self):
+        out = np.zeros(12, np.uint64)
+        _check(lib.rt_sched_stats(self.h, _p(out)))
+        names = ("box_votes", "prim", "shade", "newpath", "newpixel", "box_steps")
+        return {n: (int(out[2 * i]), int(out[2 * i + 1])) for i, n in enumerate(names)}
 
     def last_render_ms(self):
         ms = C.c_float()

@@ -16,6 +16,7 @@
 
 namespace rt {
 hipError_t launchRender(const RenderArgs& a, bool lds, bool count, int blocks, int threads, hipStream_t stream);
+hipError_t launchWavefront(const RenderArgs& a, bool lds, bool count, int blocks, int threads, hipStream_t stream);
 hipError_t launchTrace(const DevScene& sc, int n, const float* rays, int* kind, int* id, float* t, float* normal,
                        int* front, float* uv, hipStream_t stream);
 hipError_t launchScatter(const DevScene& sc, int n, const int* mat, const float* rayIn, const float* p, const float* nrm,
@@ -48,6 +49,7 @@ struct rt_context {
     unsigned int* queue = nullptr;
     unsigned long long* counters = nullptr;
     std::atomic<int> cancel{0};
+    unsigned long long sched_stats[12] = {0};  // from the last rt_count(): {executions, lanes} per operation
 };
 
 namespace {
@@ -130,20 +132,33 @@ int checkRenderState(rt_context* ctx) {
     return RT_OK;
 }
 
+// Launch shape.  Default: the persistent wavefront loop, a fixed number of 256-thread
+// workgroups per CU that pull pixels from a queue.  RT_KERNEL=simple selects the plain
+// one-wave-per-tile kernel (kept for A/B measurements); both produce identical images.
 int launch(rt_context* ctx, rt::RenderArgs& a, bool count) {
     const int threads = 256;
     const int wavesPerBlock = threads / 64;
+    const char* kernel = std::getenv("RT_KERNEL");
+    const bool simple = kernel && std::strcmp(kernel, "simple") == 0;
     int blocks;
-    const bool persistent = envInt("RT_PERSISTENT", 0) != 0;
-    if (persistent) {
-        HIP_TRY(hipMemsetAsync(ctx->queue, 0, sizeof(unsigned int), ctx->stream));
-        a.queue = ctx->queue;
-        blocks = ctx->n_cus * envInt("RT_BLOCKS_PER_CU", 2);
-    } else {
+    if (simple) {
         blocks = (a.n_local_tiles + wavesPerBlock - 1) / wavesPerBlock;
+        if (blocks < 1) blocks = 1;
+        HIP_TRY(rt::launchRender(a, ctx->use_lds, count, blocks, threads, ctx->stream));
+        return RT_OK;
     }
+    HIP_TRY(hipMemsetAsync(ctx->queue, 0, 256, ctx->stream));
+    a.queue = ctx->queue;
+    a.knob[0] = envInt("RT_BOX_KEEP", 24);
+    a.knob[1] = envInt("RT_SHADE_MIN", 32);
+    int wfThreads = envInt("RT_THREADS", 512);
+    if (wfThreads != 256 && wfThreads != 512 && wfThreads != 1024) wfThreads = 512;
+    const int wfWaves = wfThreads / 64;
+    blocks = ctx->n_cus * envInt("RT_BLOCKS_PER_CU", 3);
+    const int needed = (a.n_local_tiles + wfWaves - 1) / wfWaves;
+    if (blocks > needed) blocks = needed;
     if (blocks < 1) blocks = 1;
-    HIP_TRY(rt::launchRender(a, ctx->use_lds, count, blocks, threads, ctx->stream));
+    HIP_TRY(rt::launchWavefront(a, ctx->use_lds, count, blocks, wfThreads, ctx->stream));
     return RT_OK;
 }
 
@@ -257,7 +272,7 @@ int rt_scene_flatten(rt_scene* s, rt_flat_info* info) {
         info->n_textures = (int)sc.textures.size();
         info->max_leaf = sc.flat.max_leaf;
         info->fits_lds =
-            rt::ldsSceneBytes(info->n_nodes, info->n_prim_refs, info->n_spheres, info->n_triangles) <= kMaxLdsScene;
+            rt::ldsSceneBytes(info->n_nodes, info->n_prim_refs, info->n_spheres, info->n_triangles, info->n_materials) <= kMaxLdsScene;
     }
     return RT_OK;
 }
@@ -426,10 +441,11 @@ int rt_upload_scene(rt_context* ctx, rt_scene* s) {
     d.n_prim_refs = (int)sc.flat.prim_refs.size();
     d.n_spheres = (int)sc.spheres.size();
     d.n_tris = (int)sc.triangles.size();
+    d.n_mats = (int)sc.materials.size();
     std::memcpy(d.cam, &sc.camera, sizeof(float) * 22);
     std::memcpy(d.bg, sc.background, sizeof(float) * 3);
     ctx->dsc = d;
-    ctx->lds_need = rt::ldsSceneBytes(d.n_nodes, d.n_prim_refs, d.n_spheres, d.n_tris);
+    ctx->lds_need = rt::ldsSceneBytes(d.n_nodes, d.n_prim_refs, d.n_spheres, d.n_tris, d.n_mats);
     ctx->use_lds = ctx->lds_need <= kMaxLdsScene && envInt("RT_LDS", 1) != 0;
     ctx->scene_loaded = true;
     return RT_OK;
@@ -659,14 +675,14 @@ int rt_count(rt_context* ctx, int first_sample, int n_samples, int max_depth, rt
     float4* scratch = nullptr;
     HIP_TRY(hipMalloc((void**)&scratch, bytes));
     hipError_t e = hipMemsetAsync(scratch, 0, bytes, ctx->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(ctx->counters, 0, 13 * sizeof(unsigned long long), ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(ctx->counters, 0, 256, ctx->stream);
     int rcl = RT_OK;
     if (e == hipSuccess) {
         rt::RenderArgs a = makeArgs(ctx, first_sample, n_samples, max_depth);
         a.accum = scratch;
         rcl = launch(ctx, a, true);
     }
-    unsigned long long host[13] = {0};
+    unsigned long long host[32] = {0};
     if (e == hipSuccess && rcl == RT_OK)
         e = hipMemcpyAsync(host, ctx->counters, sizeof host, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -686,6 +702,13 @@ int rt_count(rt_context* ctx, int first_sample, int n_samples, int max_depth, rt
     out->scatter_pbr = host[10];
     out->misses = host[11];
     out->depth_cutoffs = host[12];
+    std::memcpy(ctx->sched_stats, host + 13, sizeof ctx->sched_stats);
+    return RT_OK;
+}
+
+int rt_sched_stats(rt_context* ctx, uint64_t* out12) {
+    if (!ctx || !out12) return fail(RT_ERR_INVALID, "bad arguments");
+    for (int i = 0; i < 12; i++) out12[i] = ctx->sched_stats[i];
     return RT_OK;
 }
 

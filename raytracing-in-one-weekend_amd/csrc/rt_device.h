@@ -19,7 +19,7 @@ struct DevScene {
     const uint32_t* texels;   // all textures, RGBX8, one dword per texel
     const int4* tex_desc;     // {first texel, width, height, 0}
     const float* lut;         // 256-entry 8-bit -> float map
-    int n_nodes, n_prim_refs, n_spheres, n_tris;
+    int n_nodes, n_prim_refs, n_spheres, n_tris, n_mats;
     float cam[22];            // origin, lowerLeftCorner, horizontal, vertical, u, v, w, lensRadius
     float bg[3];
 };
@@ -36,15 +36,17 @@ struct RenderArgs {
     int rank, world;
     int first_sample, n_samples, max_depth;
     int lds_bytes;
+    int knob[4];  // scheduling thresholds of the wavefront loop (never affect results)
 };
 
 constexpr int kTile = 8;  // one wave64 = one 8x8 pixel tile
 
-// Bytes of LDS the staged traversal data needs (nodes, leaf references, spheres, triangle
-// intersection records), each block 16-byte aligned.
-inline size_t ldsSceneBytes(int n_nodes, int n_refs, int n_spheres, int n_tris) {
+// Bytes of LDS the staged scene tables need (nodes, leaf references, spheres, triangle
+// intersection records, per-primitive material indices, materials), each block 16-byte aligned.
+inline size_t ldsSceneBytes(int n_nodes, int n_refs, int n_spheres, int n_tris, int n_mats) {
     auto al = [](size_t x) { return (x + 15) & ~size_t(15); };
-    return al((size_t)n_nodes * 32) + al((size_t)n_refs * 4) + al((size_t)n_spheres * 16) + al((size_t)n_tris * 48);
+    return al((size_t)n_nodes * 32) + al((size_t)n_refs * 4) + al((size_t)n_spheres * 16) + al((size_t)n_tris * 48) +
+           al((size_t)n_spheres * 4) + al((size_t)n_tris * 4) + al((size_t)n_mats * 32);
 }
 
 }  // namespace rt

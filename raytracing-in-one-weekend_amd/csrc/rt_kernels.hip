@@ -83,7 +83,14 @@ struct SceneView {
     const uint32_t* refs;
     const float4* spheres;
     const float4* tris;
+    const int* sphere_mat;
+    const int* tri_mat;
+    const float4* materials;
 };
+
+__device__ __forceinline__ SceneView globalView(const DevScene& sc) {
+    return SceneView{sc.nodes, sc.prim_refs, sc.spheres, sc.tri_isect, sc.sphere_mat, sc.tri_mat, sc.materials};
+}
 
 struct Stats {
     unsigned long long v[13];
@@ -100,11 +107,84 @@ struct Hit {
     float bu, bv;  // barycentrics of the accepted triangle hit
 };
 
+// AABB::Hit (R/src/AccelerationStructures/AABB.h:10-24) with tMin = 0.001 and the running
+// closest hit as tMax.  `t0 > tMin ? t0 : tMin` keeps tMin when t0 is NaN, which is fmaxf's
+// behaviour too (tMin and tMax themselves are never NaN), and the per-axis early exits are
+// equivalent to one test at the end because tMin only grows and tMax only shrinks.
+__device__ __forceinline__ bool slabPass(const float4& n0, const float4& n1, const Ray& r, float invx, float invy,
+                                         float invz, float closest) {
+    float t0 = (n0.x - r.o.x) * invx, t1 = (n1.x - r.o.x) * invx;
+    if (invx < 0.0f) { float s = t0; t0 = t1; t1 = s; }
+    float tmin = fmaxf(t0, kTMin), tmax = fminf(t1, closest);
+    t0 = (n0.y - r.o.y) * invy; t1 = (n1.y - r.o.y) * invy;
+    if (invy < 0.0f) { float s = t0; t0 = t1; t1 = s; }
+    tmin = fmaxf(t0, tmin); tmax = fminf(t1, tmax);
+    t0 = (n0.z - r.o.z) * invz; t1 = (n1.z - r.o.z) * invz;
+    if (invz < 0.0f) { float s = t0; t0 = t1; t1 = s; }
+    tmin = fmaxf(t0, tmin); tmax = fminf(t1, tmax);
+    return !(tmax <= tmin);
+}
+
+// One primitive against the ray with the running closest hit as tMax.  A later primitive
+// wins a tie in t (`tMax < t` rejects, equality accepts), as in the reference.
+template <bool COUNT>
+__device__ __forceinline__ void primTest(const SceneView& sv, uint32_t ref, const Ray& r, float a, Hit& h, Stats* st) {
+    const uint32_t id = ref & kRefId;
+    if (ref & kRefTri) {
+        // Triangle::Hit, R/src/Core/Hittable.h:58-141 (edges are precomputed on the host with the
+        // same two subtractions)
+        if (COUNT) st->v[C_TRI]++;
+        const float4 q0 = sv.tris[3 * id], q1 = sv.tris[3 * id + 1], q2 = sv.tris[3 * id + 2];
+        const V3 v0{q0.x, q0.y, q0.z}, e1{q1.x, q1.y, q1.z}, e2{q2.x, q2.y, q2.z};
+        const float EPS = 1e-8f;
+        V3 hh = cross(r.d, e2);
+        float det = dot(e1, hh);
+        if (!(det > -EPS && det < EPS)) {
+            float f = 1.0f / det;
+            V3 s = r.o - v0;
+            float u = f * dot(s, hh);
+            if (!(u < 0.0f || u > 1.0f)) {
+                V3 q = cross(s, e1);
+                float v = f * dot(r.d, q);
+                if (!(v < 0.0f || u + v > 1.0f)) {
+                    float t = f * dot(e2, q);
+                    if (!(t < kTMin || h.t < t) && (t > EPS)) {
+                        h.t = t;
+                        h.ref = ref & ~kRefLast;
+                        h.bu = u;
+                        h.bv = v;
+                    }
+                }
+            }
+        }
+    } else {
+        // Sphere::Hit, R/src/Core/Hittable.h:228-255
+        if (COUNT) st->v[C_SPHERE]++;
+        const float4 s = sv.spheres[id];
+        V3 oc{r.o.x - s.x, r.o.y - s.y, r.o.z - s.z};
+        float halfB = dot(oc, r.d);
+        float c = dot(oc, oc) - s.w * s.w;
+        float disc = halfB * halfB - a * c;
+        if (!(disc < 0)) {
+            float sq = sqrtf(disc);
+            float root = (-halfB - sq) / a;
+            bool ok = true;
+            if (root < kTMin || h.t < root) {
+                root = (-halfB + sq) / a;
+                if (root < kTMin || h.t < root) ok = false;
+            }
+            if (ok) {
+                h.t = root;
+                h.ref = ref & ~kRefLast;
+            }
+        }
+    }
+}
+
 // Closest hit along the threaded, reference-ordered node array.  Entry i: box test with the
-// running closest distance as tMax (AABB::Hit, R/src/AccelerationStructures/AABB.h:10-24;
-// BVHNode::Hit passes rec.t of the left child on to the right one, Bvh.h:84-85, which is the
-// running closest hit); on a miss jump to `skip`, else test the entry's leaf run and go to
-// i + 1.  A later primitive wins a tie in t (`tMax < t` rejects, equality accepts).
+// running closest distance as tMax (BVHNode::Hit passes rec.t of the left child on to the right
+// one, R/src/AccelerationStructures/Bvh.h:84-85, which is the running closest hit); on a miss
+// jump to `skip`, else test the entry's leaf run and go to i + 1.
 template <bool COUNT>
 __device__ __forceinline__ Hit traverse(const SceneView& sv, int n_nodes, const Ray& r, Stats* st) {
     Hit h;
@@ -122,23 +202,7 @@ __device__ __forceinline__ Hit traverse(const SceneView& sv, int n_nodes, const 
         bool pass = true;
         if (!(w3 & kNoBox)) {
             if (COUNT) st->v[C_NODE]++;
-            float tmin = kTMin, tmax = h.t;
-            float t0 = (n0.x - r.o.x) * invx, t1 = (n1.x - r.o.x) * invx;
-            if (invx < 0.0f) { float s = t0; t0 = t1; t1 = s; }
-            tmin = t0 > tmin ? t0 : tmin;
-            tmax = t1 < tmax ? t1 : tmax;
-            bool fail = tmax <= tmin;
-            t0 = (n0.y - r.o.y) * invy; t1 = (n1.y - r.o.y) * invy;
-            if (invy < 0.0f) { float s = t0; t0 = t1; t1 = s; }
-            tmin = t0 > tmin ? t0 : tmin;
-            tmax = t1 < tmax ? t1 : tmax;
-            fail = fail || (tmax <= tmin);
-            t0 = (n0.z - r.o.z) * invz; t1 = (n1.z - r.o.z) * invz;
-            if (invz < 0.0f) { float s = t0; t0 = t1; t1 = s; }
-            tmin = t0 > tmin ? t0 : tmin;
-            tmax = t1 < tmax ? t1 : tmax;
-            fail = fail || (tmax <= tmin);
-            pass = !fail;
+            pass = slabPass(n0, n1, r, invx, invy, invz, h.t);
         }
         if (pass) {
             if (first >= 0) {
@@ -146,56 +210,7 @@ __device__ __forceinline__ Hit traverse(const SceneView& sv, int n_nodes, const 
                 uint32_t ref;
                 do {
                     ref = sv.refs[p++];
-                    const uint32_t id = ref & kRefId;
-                    if (ref & kRefTri) {
-                        // Triangle::Hit, R/src/Core/Hittable.h:58-141 (edges are precomputed on the
-                        // host with the same two subtractions)
-                        if (COUNT) st->v[C_TRI]++;
-                        const float4 q0 = sv.tris[3 * id], q1 = sv.tris[3 * id + 1], q2 = sv.tris[3 * id + 2];
-                        const V3 v0{q0.x, q0.y, q0.z}, e1{q1.x, q1.y, q1.z}, e2{q2.x, q2.y, q2.z};
-                        const float EPS = 1e-8f;
-                        V3 hh = cross(r.d, e2);
-                        float det = dot(e1, hh);
-                        if (!(det > -EPS && det < EPS)) {
-                            float f = 1.0f / det;
-                            V3 s = r.o - v0;
-                            float u = f * dot(s, hh);
-                            if (!(u < 0.0f || u > 1.0f)) {
-                                V3 q = cross(s, e1);
-                                float v = f * dot(r.d, q);
-                                if (!(v < 0.0f || u + v > 1.0f)) {
-                                    float t = f * dot(e2, q);
-                                    if (!(t < kTMin || h.t < t) && (t > EPS)) {
-                                        h.t = t;
-                                        h.ref = ref & ~kRefLast;
-                                        h.bu = u;
-                                        h.bv = v;
-                                    }
-                                }
-                            }
-                        }
-                    } else {
-                        // Sphere::Hit, R/src/Core/Hittable.h:228-255
-                        if (COUNT) st->v[C_SPHERE]++;
-                        const float4 s = sv.spheres[id];
-                        V3 oc{r.o.x - s.x, r.o.y - s.y, r.o.z - s.z};
-                        float halfB = dot(oc, r.d);
-                        float c = dot(oc, oc) - s.w * s.w;
-                        float disc = halfB * halfB - a * c;
-                        if (!(disc < 0)) {
-                            float sq = sqrtf(disc);
-                            float root = (-halfB - sq) / a;
-                            bool ok = true;
-                            if (root < kTMin || h.t < root) {
-                                root = (-halfB + sq) / a;
-                                if (root < kTMin || h.t < root) ok = false;
-                            }
-                            if (ok) {
-                                h.t = root;
-                                h.ref = ref & ~kRefLast;
-                            }
-                        }
-                    }
+                    primTest<COUNT>(sv, ref, r, a, h, st);
                 } while (!(ref & kRefLast));
             }
             idx = idx + 1;
@@ -245,14 +260,14 @@ __device__ __forceinline__ Surface surfaceAt(const DevScene& sc, const SceneView
             s.u = u;
             s.v = v;
         }
-        s.mat = sc.tri_mat[id];
+        s.mat = sv.tri_mat[id];
     } else {
         const float4 sp = sv.spheres[id];
         V3 c{sp.x, sp.y, sp.z};
         V3 outward = (s.p - c) / sp.w;
         s.front = dot(r.d, outward) < 0;
         s.n = s.front ? outward : -outward;
-        s.mat = sc.sphere_mat[id];
+        s.mat = sv.sphere_mat[id];
     }
     return s;
 }
@@ -274,9 +289,9 @@ __device__ __forceinline__ V3 textureAt(const DevScene& sc, int tex, float u, fl
 // Material::scatter for the five material kinds (R/src/Material/Material.h:22-160).
 // Returns true if the path continues with `out` and `atten`; false ends it with `emit`.
 template <bool COUNT>
-__device__ __forceinline__ bool scatter(const DevScene& sc, const Ray& in, const Surface& s, Rng& rng, Ray& out,
-                                        V3& atten, V3& emit, Stats* st) {
-    const float4 m0 = sc.materials[2 * s.mat], m1 = sc.materials[2 * s.mat + 1];
+__device__ __forceinline__ bool scatter(const DevScene& sc, const SceneView& sv, const Ray& in, const Surface& s,
+                                        Rng& rng, Ray& out, V3& atten, V3& emit, Stats* st) {
+    const float4 m0 = sv.materials[2 * s.mat], m1 = sv.materials[2 * s.mat + 1];
     const int kind = (int)fbits(m1.x);
     emit = {0.0f, 0.0f, 0.0f};
     out.o = s.p;
@@ -391,7 +406,7 @@ __device__ __forceinline__ V3 rayColor(const DevScene& sc, const SceneView& sv, 
         Surface s = surfaceAt(sc, sv, r, h);
         Ray out;
         V3 atten, emit;
-        if (!scatter<COUNT>(sc, r, s, rng, out, atten, emit, st)) return throughput * emit;
+        if (!scatter<COUNT>(sc, sv, r, s, rng, out, atten, emit, st)) return throughput * emit;
         throughput = throughput * atten;
         r = out;
         depth--;
@@ -400,24 +415,36 @@ __device__ __forceinline__ V3 rayColor(const DevScene& sc, const SceneView& sv, 
 
 extern __shared__ float4 rt_lds[];
 
-// Stages nodes, leaf references, spheres and triangle intersection records into LDS and
-// returns views into it (layout = ldsSceneBytes()).
+// Stages the traversal and shading tables (nodes, leaf references, spheres, triangle
+// intersection records, material indices, materials) into LDS and returns views into it
+// (layout = ldsSceneBytes()).
 __device__ __forceinline__ SceneView stageScene(const DevScene& sc) {
     auto al = [](int x) { return (x + 15) & ~15; };
     char* base = reinterpret_cast<char*>(rt_lds);
-    const int nb = al(sc.n_nodes * 32), rb = al(sc.n_prim_refs * 4), sb = al(sc.n_spheres * 16), tb = al(sc.n_tris * 48);
-    float4* nodes = reinterpret_cast<float4*>(base);
-    uint32_t* refs = reinterpret_cast<uint32_t*>(base + nb);
-    float4* spheres = reinterpret_cast<float4*>(base + nb + rb);
-    float4* tris = reinterpret_cast<float4*>(base + nb + rb + sb);
+    int off = 0;
+    float4* nodes = reinterpret_cast<float4*>(base + off);
+    off += al(sc.n_nodes * 32);
+    uint32_t* refs = reinterpret_cast<uint32_t*>(base + off);
+    off += al(sc.n_prim_refs * 4);
+    float4* spheres = reinterpret_cast<float4*>(base + off);
+    off += al(sc.n_spheres * 16);
+    float4* tris = reinterpret_cast<float4*>(base + off);
+    off += al(sc.n_tris * 48);
+    int* smat = reinterpret_cast<int*>(base + off);
+    off += al(sc.n_spheres * 4);
+    int* tmat = reinterpret_cast<int*>(base + off);
+    off += al(sc.n_tris * 4);
+    float4* mats = reinterpret_cast<float4*>(base + off);
     const int tid = threadIdx.x, nt = blockDim.x;
     for (int i = tid; i < sc.n_nodes * 2; i += nt) nodes[i] = sc.nodes[i];
     for (int i = tid; i < sc.n_prim_refs; i += nt) refs[i] = sc.prim_refs[i];
     for (int i = tid; i < sc.n_spheres; i += nt) spheres[i] = sc.spheres[i];
     for (int i = tid; i < sc.n_tris * 3; i += nt) tris[i] = sc.tri_isect[i];
-    (void)tb;
+    for (int i = tid; i < sc.n_spheres; i += nt) smat[i] = sc.sphere_mat[i];
+    for (int i = tid; i < sc.n_tris; i += nt) tmat[i] = sc.tri_mat[i];
+    for (int i = tid; i < sc.n_mats * 2; i += nt) mats[i] = sc.materials[i];
     __syncthreads();
-    return SceneView{nodes, refs, spheres, tris};
+    return SceneView{nodes, refs, spheres, tris, smat, tmat, mats};
 }
 
 // Pixel loops of RaytracerNormal::Run (R/src/Core/Raytracer.cpp:76-93) for the tiles this
@@ -430,7 +457,7 @@ __global__ void __launch_bounds__(256) renderKernel(RenderArgs a) {
     if (LDS) {
         sv = stageScene(sc);
     } else {
-        sv = SceneView{sc.nodes, sc.prim_refs, sc.spheres, sc.tri_isect};
+        sv = globalView(sc);
     }
     const int lane = threadIdx.x & 63;
     const int wavesPerBlock = blockDim.x >> 6;
@@ -486,12 +513,253 @@ __global__ void __launch_bounds__(256) renderKernel(RenderArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Persistent wavefront loop.
+//
+// Every lane is a small state machine that walks one pixel at a time through its samples:
+//   NEWPIXEL -> NEWPATH -> (BOX | PRIM)* -> SHADE -> (BOX ... | NEWPATH) ... -> NEWPIXEL
+// and carries the name of the operation it needs next.  Each trip round the loop the wave
+// ballots the lanes per operation, picks one operation, and runs it for exactly the lanes
+// that want it; the others wait with their state in registers.  Lanes that finish a path
+// regenerate a camera ray for their next sample, lanes that finish a pixel pull the next
+// pixel from the launch-wide queue, so no lane idles until the queue is dry.  Which lane
+// runs when never changes what a lane computes: a pixel's samples are still summed by one
+// lane in sample order, and the random stream is keyed by (x, y, sample, counter).
+enum : int { OP_BOX = 0, OP_PRIM = 1, OP_SHADE = 2, OP_NEWPATH = 3, OP_NEWPIXEL = 4, OP_DONE = 5 };
+
+__device__ __forceinline__ int popc64(unsigned long long m) { return __builtin_popcountll(m); }
+
+template <bool LDS, bool COUNT>
+__global__ void __launch_bounds__(1024) renderWavefront(RenderArgs a) {
+    const DevScene& sc = a.sc;
+    SceneView sv;
+    if (LDS) {
+        sv = stageScene(sc);
+    } else {
+        sv = globalView(sc);
+    }
+    const int lane = threadIdx.x & 63;
+    const int nNodes = sc.n_nodes;
+    const int nSlots = a.n_local_tiles * 64;
+    const int sEnd = a.first_sample + a.n_samples;
+    const int boxKeep = a.knob[0];    // keep running BOX steps while at least this many lanes want one
+    const int shadeMin = a.knob[1];   // run SHADE / NEWPATH early once this many lanes wait for it
+    Stats st;
+    if (COUNT)
+        for (int i = 0; i < 13; i++) st.v[i] = 0;
+
+    int op = OP_NEWPIXEL;
+    int q = 0, px = 0, py = 0, s = 0, depth = 0, idx = 0, p = 0;
+    V3 sum{0.f, 0.f, 0.f}, thr{1.f, 1.f, 1.f};
+    Rng rng{0u, 0u};
+    Ray r{{0.f, 0.f, 0.f}, {0.f, 0.f, 1.f}};
+    float invx = 0.f, invy = 0.f, invz = 0.f, aa = 1.f;
+    Hit h{0.f, kNoHit, 0.f, 0.f};
+
+    // wave-local pool of pixel slots pulled from the launch-wide queue 64 at a time
+    int poolNext = 0, poolEnd = 0;
+    unsigned long long schedExec[6] = {0, 0, 0, 0, 0, 0}, schedLanes[6] = {0, 0, 0, 0, 0, 0};
+
+    auto startRay = [&]() {
+        invx = 1.0f / r.d.x;
+        invy = 1.0f / r.d.y;
+        invz = 1.0f / r.d.z;
+        aa = dot(r.d, r.d);
+        h.t = __builtin_inff();
+        h.ref = kNoHit;
+        idx = 0;
+        op = OP_BOX;
+        if (COUNT) st.v[C_RAYS]++;
+    };
+    auto endPath = [&](V3 terminal) {
+        V3 c = thr * terminal;
+        sum = sum + c;
+        s += 1;
+        op = OP_NEWPATH;
+    };
+
+    for (;;) {
+        const unsigned long long mBox = __ballot(op == OP_BOX);
+        const unsigned long long mPrim = __ballot(op == OP_PRIM);
+        const unsigned long long mShade = __ballot(op == OP_SHADE);
+        const unsigned long long mPath = __ballot(op == OP_NEWPATH);
+        const unsigned long long mPixel = __ballot(op == OP_NEWPIXEL);
+        const int cBox = popc64(mBox), cPrim = popc64(mPrim), cShade = popc64(mShade), cPath = popc64(mPath),
+                  cPixel = popc64(mPixel);
+        if ((cBox | cPrim | cShade | cPath | cPixel) == 0) break;
+
+        // Pick the operation to run: the cheap bookkeeping ones first, then whichever of the
+        // traversal / shading operations has the most lanes waiting (shading is the costly one,
+        // so it also goes as soon as `shadeMin` lanes have piled up).
+        int chosen;
+        if (cPixel > 0 && (cPixel >= 16 || (cBox | cPrim | cShade | cPath) == 0)) {
+            chosen = OP_NEWPIXEL;
+        } else if (cShade >= shadeMin || cPath >= shadeMin) {
+            chosen = cShade >= cPath ? OP_SHADE : OP_NEWPATH;
+        } else {
+            chosen = OP_BOX;
+            int best = cBox;
+            if (cPrim > best) { best = cPrim; chosen = OP_PRIM; }
+            if (cShade > best) { best = cShade; chosen = OP_SHADE; }
+            if (cPath > best) { best = cPath; chosen = OP_NEWPATH; }
+            if (best == 0) chosen = OP_NEWPIXEL;
+        }
+
+        if (COUNT) {  // scheduling statistics: executions and waiting lanes per operation
+            const int cnt[5] = {cBox, cPrim, cShade, cPath, cPixel};
+            schedExec[chosen] += 1;
+            schedLanes[chosen] += cnt[chosen];
+        }
+        if (chosen == OP_BOX) {
+            int keep = boxKeep < cBox ? boxKeep : cBox;  // never spin below what is available
+            do {
+                if (COUNT) {
+                    schedExec[5] += 1;
+                    schedLanes[5] += popc64(__ballot(op == OP_BOX));
+                }
+                if (op == OP_BOX) {
+                    const float4 n0 = sv.nodes[2 * idx], n1 = sv.nodes[2 * idx + 1];
+                    const uint32_t w3 = fbits(n0.w);
+                    const int first = (int)fbits(n1.w);
+                    // the box is tested even for list entries (whose box words are zero) so that
+                    // both node words are fetched together; the flag then overrides the outcome
+                    const bool nobox = (w3 & kNoBox) != 0;
+                    if (COUNT && !nobox) st.v[C_NODE]++;
+                    const bool pass = slabPass(n0, n1, r, invx, invy, invz, h.t) || nobox;
+                    if (pass) {
+                        if (first >= 0) {
+                            p = first;
+                            op = OP_PRIM;
+                        } else {
+                            idx += 1;
+                        }
+                    } else {
+                        idx = (int)(w3 & kSkipMask);
+                    }
+                    if (op == OP_BOX && idx >= nNodes) op = OP_SHADE;
+                }
+            } while (popc64(__ballot(op == OP_BOX)) >= keep && keep > 0);
+        } else if (chosen == OP_PRIM) {
+            if (op == OP_PRIM) {
+                const uint32_t ref = sv.refs[p];
+                primTest<COUNT>(sv, ref, r, aa, h, &st);
+                if (ref & kRefLast) {
+                    idx += 1;
+                    op = idx < nNodes ? OP_BOX : OP_SHADE;
+                } else {
+                    p += 1;
+                }
+            }
+        } else if (chosen == OP_SHADE) {
+            if (op == OP_SHADE) {
+                if (h.ref == kNoHit) {
+                    if (COUNT) st.v[C_MISS]++;
+                    endPath(V3{sc.bg[0], sc.bg[1], sc.bg[2]});
+                } else {
+                    if (COUNT) st.v[C_HITS]++;
+                    Surface sf = surfaceAt(sc, sv, r, h);
+                    Ray out;
+                    V3 atten, emit;
+                    if (!scatter<COUNT>(sc, sv, r, sf, rng, out, atten, emit, &st)) {
+                        endPath(emit);
+                    } else {
+                        thr = thr * atten;
+                        r = out;
+                        depth -= 1;
+                        if (depth <= 0) {
+                            if (COUNT) st.v[C_CUTOFF]++;
+                            endPath(V3{0.0f, 0.0f, 0.0f});
+                        } else {
+                            startRay();
+                        }
+                    }
+                }
+            }
+        } else if (chosen == OP_NEWPATH) {
+            if (op == OP_NEWPATH) {
+                if (s >= sEnd) {
+                    a.accum[q] = make_float4(sum.x, sum.y, sum.z, (float)sEnd);
+                    op = OP_NEWPIXEL;
+                } else {
+                    rng.init((uint32_t)px, (uint32_t)py, s);
+                    if (COUNT) st.v[C_SAMPLES]++;
+                    // u is drawn before v (R/src/Core/Raytracer.cpp:86-87)
+                    float u = ((float)px + rng.next()) / (float)(a.width - 1);
+                    float v = ((float)py + rng.next()) / (float)(a.height - 1);
+                    r = cameraRay(sc, u, v, rng);
+                    thr = V3{1.0f, 1.0f, 1.0f};
+                    depth = a.max_depth;
+                    if (depth <= 0) {
+                        if (COUNT) st.v[C_CUTOFF]++;
+                        endPath(V3{0.0f, 0.0f, 0.0f});
+                    } else {
+                        startRay();
+                    }
+                }
+            }
+        } else {  // OP_NEWPIXEL: hand the waiting lanes the next pixel slots, in lane order
+            const bool want = op == OP_NEWPIXEL;
+            const unsigned long long m = __ballot(want);
+            const int need = popc64(m);
+            if (poolEnd >= 0 && poolNext >= poolEnd) {  // pool used up: pull the next 64 slots
+                unsigned int base = 0;
+                if (lane == 0) base = atomicAdd(a.queue, 64u);
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (base >= (unsigned int)nSlots) {
+                    poolNext = poolEnd = -1;  // the queue is dry
+                } else {
+                    poolNext = (int)base;
+                    poolEnd = (int)base + 64 < nSlots ? (int)base + 64 : nSlots;
+                }
+            }
+            const int avail = poolEnd < 0 ? 0 : poolEnd - poolNext;
+            if (want) {
+                const int rankInMask =
+                    __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                if (poolEnd < 0) {
+                    op = OP_DONE;
+                } else if (rankInMask < avail) {
+                    q = poolNext + rankInMask;
+                    const int tile = q >> 6, l = q & 63;
+                    const int ty = tile / a.tiles_per_row_local;
+                    const int k = tile - ty * a.tiles_per_row_local;
+                    int base = (a.rank - ty) % a.world;
+                    if (base < 0) base += a.world;
+                    const int tx = base + k * a.world;
+                    px = tx * kTile + (l & 7);
+                    py = ty * kTile + (l >> 3);
+                    if (tx < a.tiles_x && px < a.width && py < a.height) {
+                        const float4 acc = a.accum[q];
+                        sum = V3{acc.x, acc.y, acc.z};
+                        s = a.first_sample;
+                        op = OP_NEWPATH;
+                    }  // else a padding slot outside the image: this lane asks again
+                }      // else the pool ran out before this lane's turn: it asks again
+            }
+            poolNext += need < avail ? need : avail;
+        }
+    }
+    if (COUNT && lane == 0) {
+        for (int i = 0; i < 6; i++) {
+            atomicAdd(&a.counters[13 + 2 * i], schedExec[i]);
+            atomicAdd(&a.counters[14 + 2 * i], schedLanes[i]);
+        }
+    }
+    if (COUNT) {
+        for (int i = 0; i < 13; i++) {
+            unsigned long long v = st.v[i];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+            if (lane == 0 && v) atomicAdd(&a.counters[i], v);
+        }
+    }
+}
+
 // Closest hit + hit record of arbitrary rays (test hook behind rt_trace).
 __global__ void __launch_bounds__(256) traceKernel(DevScene sc, int n, const float* rays, int* kind, int* id, float* t,
                                                    float* normal, int* front, float* uv) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    SceneView sv{sc.nodes, sc.prim_refs, sc.spheres, sc.tri_isect};
+    SceneView sv = globalView(sc);
     Ray r;
     r.o = {rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]};
     r.d = {rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]};
@@ -540,7 +808,7 @@ __global__ void scatterKernel(DevScene sc, int n, const int* mat, const float* r
     out.o = {0, 0, 0};
     out.d = {0, 0, 0};
     V3 att{0, 0, 0}, emit;
-    bool ok = scatter<false>(sc, in, s, rng, out, att, emit, nullptr);
+    bool ok = scatter<false>(sc, globalView(sc), in, s, rng, out, att, emit, nullptr);
     atten[3 * i] = att.x;
     atten[3 * i + 1] = att.y;
     atten[3 * i + 2] = att.z;
@@ -587,6 +855,23 @@ __global__ void __launch_bounds__(256) resolveKernel(const float4* payloads, siz
 }
 
 // ------------------------------------------------------------------ launch wrappers
+template <bool LDS, bool COUNT>
+static hipError_t launchWavefrontT(const RenderArgs& a, int blocks, int threads, size_t shmem, hipStream_t stream) {
+    if (LDS)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(renderWavefront<LDS, COUNT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    renderWavefront<LDS, COUNT><<<blocks, threads, shmem, stream>>>(a);
+    return hipGetLastError();
+}
+
+hipError_t launchWavefront(const RenderArgs& a, bool lds, bool count, int blocks, int threads, hipStream_t stream) {
+    size_t shmem = lds ? (size_t)a.lds_bytes : 0;
+    if (lds) return count ? launchWavefrontT<true, true>(a, blocks, threads, shmem, stream)
+                          : launchWavefrontT<true, false>(a, blocks, threads, shmem, stream);
+    return count ? launchWavefrontT<false, true>(a, blocks, threads, 0, stream)
+                 : launchWavefrontT<false, false>(a, blocks, threads, 0, stream);
+}
+
 hipError_t launchRender(const RenderArgs& a, bool lds, bool count, int blocks, int threads, hipStream_t stream) {
     size_t shmem = lds ? (size_t)a.lds_bytes : 0;
     if (lds && !count) {
