@@ -148,6 +148,12 @@ void rt_destroy(rt_context* ctx);
  * are ordered on one stream without host synchronisation.  NULL restores the context's stream. */
 int rt_set_stream(rt_context* ctx, void* hip_stream);
 
+/* Diagnostics: with on = 1 every ray walks the flattened node array in the reference's order
+ * (BVHNode::Hit, R/src/AccelerationStructures/Bvh.h:80-88).  With on = 0 (default) rays first
+ * search a tighter tree over the same primitives and fall back to that walk only when the
+ * guard test of the winner fails; both settings return identical hits.  Applies to later calls. */
+int rt_set_reference_traversal(rt_context* ctx, int on);
+
 /* Copies the flattened scene, camera and background to the device (replaces what
  * `Raytracer`'s constructor captures from Scene&, Raytracer.h:27-31). */
 int rt_upload_scene(rt_context* ctx, rt_scene* s);
@@ -212,18 +218,21 @@ int rt_scatter_test(rt_context* ctx, int n, const int32_t* material, const float
 
 /* Path statistics of one counting pass over the owned pixels (same paths as rt_render):
  * samples, rays, node tests, sphere tests, triangle tests, hits, scatters by material kind
- * (lambertian, metal, dielectric, light, pbr), misses, depth cut-offs.  Blocking. */
+ * (lambertian, metal, dielectric, light, pbr), misses, depth cut-offs.  Node and primitive
+ * test counts are those of the traversal actually run (see rt_set_reference_traversal).  Blocking. */
 typedef struct rt_counters {
     uint64_t samples, rays, node_tests, sphere_tests, tri_tests, hits;
     uint64_t scatter_lambertian, scatter_metal, scatter_dielectric, scatter_light, scatter_pbr;
     uint64_t misses, depth_cutoffs;
+    uint64_t fallbacks; /* rays re-traced in the reference's order (guard test failed, NaN, zero direction component) */
 } rt_counters;
 int rt_count(rt_context* ctx, int first_sample, int n_samples, int max_depth, rt_counters* out);
 
 /* Diagnostics of the wavefront scheduler, filled by the last rt_count(): for each lane operation
- * (box test, primitive test, shade, new path, new pixel, and box steps inside a burst) the number
- * of wave-level executions and the number of lanes that took part.  No reference counterpart. */
-int rt_sched_stats(rt_context* ctx, uint64_t* out12);
+ * (box test, primitive test, shade, sphere-sample attempt, new path, disk-sample attempt, new
+ * pixel) the number of wave-level executions and the number of lanes that took part: 7 pairs.
+ * No reference counterpart. */
+int rt_sched_stats(rt_context* ctx, uint64_t* out14);
 
 /* Milliseconds the last rt_render() kernel took on the device (HIP events on the context's
  * stream).  Blocks until that kernel has finished. */

@@ -32,7 +32,7 @@ class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "samples", "rays", "node_tests", "sphere_tests", "tri_tests", "hits",
         "scatter_lambertian", "scatter_metal", "scatter_dielectric", "scatter_light", "scatter_pbr",
-        "misses", "depth_cutoffs")]
+        "misses", "depth_cutoffs", "fallbacks")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
@@ -73,6 +73,7 @@ SYMBOLS = {
     "rt_create": (_I, [_I, C.POINTER(_VP)]),
     "rt_destroy": (None, [_VP]),
     "rt_set_stream": (_I, [_VP, _VP]),
+    "rt_set_reference_traversal": (_I, [_VP, _I]),
     "rt_upload_scene": (_I, [_VP, _VP]),
     "rt_set_target": (_I, [_VP, _I, _I, _I, _I]),
     "rt_set_target_external": (_I, [_VP, _I, _I, _I, _I, _VP]),
@@ -260,6 +261,9 @@ class Context:
     def set_stream(self, hip_stream):
         _check(lib.rt_set_stream(self.h, C.c_void_p(hip_stream)))
 
+    def set_reference_traversal(self, on):
+        _check(lib.rt_set_reference_traversal(self.h, 1 if on else 0))
+
     def upload_scene(self, scene):
         _check(lib.rt_upload_scene(self.h, scene.h))
 
@@ -331,9 +335,9 @@ class Context:
         return c.as_dict()
 
     def sched_stats(self):
-        out = np.zeros(12, np.uint64)
+        out = np.zeros(14, np.uint64)
         _check(lib.rt_sched_stats(self.h, _p(out)))
-        names = ("box_votes", "prim", "shade", "newpath", "newpixel", "box_steps")
+        names = ("box_votes", "prim", "shade", "newpath", "newpixel", "box_steps", "unused")
         return {n: (int(out[2 * i]), int(out[2 * i + 1])) for i, n in enumerate(names)}
 
     def last_render_ms(self):

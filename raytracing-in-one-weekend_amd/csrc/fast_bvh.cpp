@@ -1,0 +1,291 @@
+// The search structure the kernels traverse first, and the guard data that lets its answer
+// stand in for the reference's own traversal.
+//
+// Why this is allowed.  The reference finds the closest hit by walking ITS tree in ITS order
+// (R/src/AccelerationStructures/Bvh.h:80-88).  What that walk returns can be characterised
+// without doing it:
+//   * A primitive's hit distance does not depend on the tMax it is tested with: Sphere::Hit /
+//     Triangle::Hit return the same t for every tMax >= t and miss for tMax < t
+//     (R/src/Core/Hittable.h:241-246, 80-82).
+//   * AABB::Hit(r, tMin, tMax) (AABB.h:10-24) passes exactly when T1 > Tm and tMax > Tm, where
+//     Tm = max(tMin, entry distances) and T1 = min(exit distances) depend on ray and box only.
+//   * surroundingBox() nests boxes exactly (fmin/fmax), and the float expressions for the entry
+//     and exit distances are monotone in the box planes, so if a node's box passes for some
+//     tMax, every enclosing box of the same BVH passes for any tMax' >= tMax.
+// So if P is the primitive with the smallest hit distance t_P of ALL primitives (the later one
+// in the reference's visit order among exact ties), and the innermost reference box above P
+// (plus any enclosing box that does not contain it, e.g. a mesh AABB) passes with tMax = t_P,
+// then the reference's walk reaches P, accepts it (tMax >= t_P always holds there) and nothing
+// replaces it: the reference returns (P, t_P).  The kernels therefore search a tighter tree
+// (surface-area heuristic, boxes padded far beyond rounding error so that no true hit is ever
+// culled), check that condition for the winner, and re-trace the ray through the reference
+// arrays in the reference's order whenever the check fails, a distance is NaN, or a direction
+// component is zero (infinite reciprocal, where the NaN-skipping of the slab test breaks the
+// monotonicity argument).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+#include "host_scene.h"
+
+namespace rt {
+
+namespace {
+
+struct PrimBox {
+    float mn[3], mx[3];
+    uint32_t ref;  // kind flag + id, as in prim_refs (without the last-of-run bit)
+};
+
+inline float f32(uint32_t u) {
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+inline uint32_t u32(float f) {
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    return u;
+}
+
+inline float area(const float* mn, const float* mx) {
+    float dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
+    return 2.0f * (dx * dy + dy * dz + dz * dx);
+}
+
+struct Builder {
+    std::vector<PrimBox>& prims;
+    std::vector<uint32_t>& nodes;
+    std::vector<uint32_t>& refs;
+    static constexpr int kBins = 16;
+    static constexpr int kMaxLeaf = 2;
+
+    int newEntry(const float* mn, const float* mx) {
+        int idx = (int)(nodes.size() / 8);
+        uint32_t w[8] = {u32(mn[0]), u32(mn[1]), u32(mn[2]), (uint32_t)(idx + 1),
+                         u32(mx[0]), u32(mx[1]), u32(mx[2]), 0xFFFFFFFFu};
+        nodes.insert(nodes.end(), w, w + 8);
+        return idx;
+    }
+
+    void build(size_t start, size_t end) {
+        float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+        float cmn[3] = {INFINITY, INFINITY, INFINITY}, cmx[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (size_t i = start; i < end; i++) {
+            for (int k = 0; k < 3; k++) {
+                mn[k] = std::min(mn[k], prims[i].mn[k]);
+                mx[k] = std::max(mx[k], prims[i].mx[k]);
+                float c = 0.5f * (prims[i].mn[k] + prims[i].mx[k]);
+                cmn[k] = std::min(cmn[k], c);
+                cmx[k] = std::max(cmx[k], c);
+            }
+        }
+        const int e = newEntry(mn, mx);
+        const size_t n = end - start;
+        size_t mid = 0;
+        bool split = n > (size_t)kMaxLeaf;
+        if (split) {
+            // binned surface-area heuristic over the centroid bounds
+            float bestCost = INFINITY;
+            int bestAxis = -1, bestBin = -1;
+            for (int ax = 0; ax < 3; ax++) {
+                const float ext = cmx[ax] - cmn[ax];
+                if (!(ext > 0)) continue;
+                float bmn[kBins][3], bmx[kBins][3];
+                int cnt[kBins] = {0};
+                for (int b = 0; b < kBins; b++)
+                    for (int k = 0; k < 3; k++) {
+                        bmn[b][k] = INFINITY;
+                        bmx[b][k] = -INFINITY;
+                    }
+                const float scale = kBins / ext;
+                for (size_t i = start; i < end; i++) {
+                    float c = 0.5f * (prims[i].mn[ax] + prims[i].mx[ax]);
+                    int b = std::min(kBins - 1, std::max(0, (int)((c - cmn[ax]) * scale)));
+                    cnt[b]++;
+                    for (int k = 0; k < 3; k++) {
+                        bmn[b][k] = std::min(bmn[b][k], prims[i].mn[k]);
+                        bmx[b][k] = std::max(bmx[b][k], prims[i].mx[k]);
+                    }
+                }
+                float rArea[kBins];
+                int rCnt[kBins];
+                float amn[3] = {INFINITY, INFINITY, INFINITY}, amx[3] = {-INFINITY, -INFINITY, -INFINITY};
+                int c = 0;
+                for (int b = kBins - 1; b > 0; b--) {
+                    for (int k = 0; k < 3; k++) {
+                        amn[k] = std::min(amn[k], bmn[b][k]);
+                        amx[k] = std::max(amx[k], bmx[b][k]);
+                    }
+                    c += cnt[b];
+                    rArea[b] = c ? area(amn, amx) : 0.0f;
+                    rCnt[b] = c;
+                }
+                for (int k = 0; k < 3; k++) {
+                    amn[k] = INFINITY;
+                    amx[k] = -INFINITY;
+                }
+                c = 0;
+                for (int b = 0; b < kBins - 1; b++) {
+                    for (int k = 0; k < 3; k++) {
+                        amn[k] = std::min(amn[k], bmn[b][k]);
+                        amx[k] = std::max(amx[k], bmx[b][k]);
+                    }
+                    c += cnt[b];
+                    if (c == 0 || rCnt[b + 1] == 0) continue;
+                    float cost = area(amn, amx) * c + rArea[b + 1] * rCnt[b + 1];
+                    if (cost < bestCost) {
+                        bestCost = cost;
+                        bestAxis = ax;
+                        bestBin = b;
+                    }
+                }
+            }
+            if (bestAxis < 0) {
+                // all centroids coincide: split by count
+                mid = start + n / 2;
+            } else {
+                const float ext = cmx[bestAxis] - cmn[bestAxis];
+                const float scale = kBins / ext;
+                auto it = std::partition(prims.begin() + start, prims.begin() + end, [&](const PrimBox& p) {
+                    float c = 0.5f * (p.mn[bestAxis] + p.mx[bestAxis]);
+                    int b = std::min(kBins - 1, std::max(0, (int)((c - cmn[bestAxis]) * scale)));
+                    return b <= bestBin;
+                });
+                mid = (size_t)(it - prims.begin());
+                if (mid == start || mid == end) mid = start + n / 2;
+            }
+        }
+        if (!split) {
+            nodes[(size_t)e * 8 + 7] = (uint32_t)refs.size();
+            for (size_t i = start; i < end; i++) refs.push_back(prims[i].ref);
+            refs.back() |= kRefLast;
+        } else {
+            // the child with the smaller box first: the big one (e.g. the ground) is then tested
+            // with a closest hit already in hand more often
+            auto rangeArea = [&](size_t a, size_t b) {
+                float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+                for (size_t i = a; i < b; i++)
+                    for (int k = 0; k < 3; k++) {
+                        lo[k] = std::min(lo[k], prims[i].mn[k]);
+                        hi[k] = std::max(hi[k], prims[i].mx[k]);
+                    }
+                return area(lo, hi);
+            };
+            if (rangeArea(start, mid) > rangeArea(mid, end)) {
+                std::rotate(prims.begin() + start, prims.begin() + mid, prims.begin() + end);
+                mid = start + (end - mid);
+            }
+            build(start, mid);
+            build(mid, end);
+        }
+        nodes[(size_t)e * 8 + 3] = (uint32_t)(nodes.size() / 8);
+    }
+};
+
+}  // namespace
+
+void Scene::buildFastStructure() {
+    FlatScene& f = flat;
+    f.fast_nodes.clear();
+    f.fast_refs.clear();
+    f.sphere_ord.assign(spheres.size(), -1);
+    f.tri_ord.assign(triangles.size(), -1);
+    const size_t nRefs = f.prim_refs.size();
+    const size_t nNodes = f.nodes.size() / 8;
+
+    // ---- reference visit order of every primitive
+    for (size_t i = 0; i < nRefs; i++) {
+        const uint32_t r = f.prim_refs[i];
+        const uint32_t id = r & kRefIdMask;
+        // a primitive that is listed twice (possible through the API) keeps its LAST position,
+        // the one that wins an exact tie in the reference's walk
+        if (r & kRefTriangle) f.tri_ord[id] = (int32_t)i; else f.sphere_ord[id] = (int32_t)i;
+    }
+
+    // ---- guards: for every leaf run the innermost box-tested entry above it, and for every
+    // box-tested entry the nearest enclosing one that does not contain its box
+    f.prim_guard.assign(nRefs, -1);
+    f.node_outer.assign(nNodes, -1);
+    std::vector<int> open;  // stack of box-tested entries whose subtree contains the current entry
+    auto box = [&](int e, float* mn, float* mx) {
+        for (int k = 0; k < 3; k++) {
+            mn[k] = f32(f.nodes[(size_t)e * 8 + k]);
+            mx[k] = f32(f.nodes[(size_t)e * 8 + 4 + k]);
+        }
+    };
+    for (size_t e = 0; e < nNodes; e++) {
+        while (!open.empty() && (f.nodes[(size_t)open.back() * 8 + 3] & kNodeSkipMask) <= e) open.pop_back();
+        const uint32_t w3 = f.nodes[e * 8 + 3];
+        const bool hasBox = !(w3 & kNodeNoBox);
+        if (hasBox) {
+            float mn[3], mx[3];
+            box((int)e, mn, mx);
+            for (int j = (int)open.size() - 1; j >= 0; j--) {
+                float amn[3], amx[3];
+                box(open[j], amn, amx);
+                bool contains = true;
+                for (int k = 0; k < 3; k++) contains = contains && amn[k] <= mn[k] && amx[k] >= mx[k];
+                if (!contains) {
+                    f.node_outer[e] = open[j];
+                    break;
+                }
+            }
+            open.push_back((int)e);
+        }
+        const int32_t first = (int32_t)f.nodes[e * 8 + 7];
+        if (first >= 0) {
+            const int guard = open.empty() ? -1 : open.back();
+            size_t p = (size_t)first;
+            for (;;) {
+                f.prim_guard[p] = guard;
+                if (f.prim_refs[p] & kRefLast) break;
+                p++;
+            }
+        }
+    }
+
+    // ---- padded primitive boxes.  The padding is orders of magnitude above the rounding error of
+    // the hit-distance arithmetic (which is worst for the radius-1000 ground sphere), so a
+    // primitive whose computed hit distance is accepted always lies inside its padded box.
+    std::vector<PrimBox> prims;
+    prims.reserve(spheres.size() + triangles.size());
+    auto pad = [](PrimBox& b) {
+        float m = 0.0f;
+        for (int k = 0; k < 3; k++) m = std::max(m, std::max(std::fabs(b.mn[k]), std::fabs(b.mx[k])));
+        const float d = 2e-4f * m + 1e-4f;
+        for (int k = 0; k < 3; k++) {
+            b.mn[k] -= d;
+            b.mx[k] += d;
+        }
+    };
+    for (size_t i = 0; i < spheres.size(); i++) {
+        if (f.sphere_ord[i] < 0) continue;  // not in the world
+        PrimBox b;
+        for (int k = 0; k < 3; k++) {
+            b.mn[k] = spheres[i].c[k] - std::fabs(spheres[i].r);
+            b.mx[k] = spheres[i].c[k] + std::fabs(spheres[i].r);
+        }
+        b.ref = (uint32_t)i;
+        pad(b);
+        prims.push_back(b);
+    }
+    for (size_t i = 0; i < triangles.size(); i++) {
+        if (f.tri_ord[i] < 0) continue;
+        PrimBox b;
+        for (int k = 0; k < 3; k++) {
+            const float a = triangles[i].pos[k], c = triangles[i].pos[3 + k], d = triangles[i].pos[6 + k];
+            b.mn[k] = std::min(a, std::min(c, d));
+            b.mx[k] = std::max(a, std::max(c, d));
+        }
+        b.ref = (uint32_t)i | kRefTriangle;
+        pad(b);
+        prims.push_back(b);
+    }
+    if (prims.empty()) return;
+    Builder bld{prims, f.fast_nodes, f.fast_refs};
+    bld.build(0, prims.size());
+}
+
+}  // namespace rt

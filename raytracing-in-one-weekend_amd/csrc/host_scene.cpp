@@ -756,6 +756,7 @@ void Scene::flatten() {
     flat.prim_refs.clear();
     flat.max_leaf = 0;
     emitObjects(world, -1);
+    buildFastStructure();
     flat.valid = true;
 }
 

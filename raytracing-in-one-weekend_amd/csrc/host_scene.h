@@ -58,6 +58,17 @@ struct FlatScene {
     std::vector<uint32_t> prim_refs;
     int max_leaf = 0;
     bool valid = false;
+
+    // The search structure the kernels traverse first (fast_bvh.cpp): a SAH BVH over all
+    // primitives with padded boxes, in the same threaded entry format.  Its answer is accepted
+    // only if the guard boxes of the hit primitive pass; otherwise the ray is traced again
+    // through `nodes` in the reference's order.
+    std::vector<uint32_t> fast_nodes;   // 8 words per entry, as `nodes`
+    std::vector<uint32_t> fast_refs;    // leaf references, as `prim_refs`
+    std::vector<int32_t> sphere_ord;    // sphere id   -> position in prim_refs (reference visit order)
+    std::vector<int32_t> tri_ord;       // triangle id -> position in prim_refs
+    std::vector<int32_t> prim_guard;    // position in prim_refs -> innermost box-tested entry of `nodes` above it, or -1
+    std::vector<int32_t> node_outer;    // entry of `nodes` -> nearest enclosing box-tested entry whose box does not contain it, or -1
 };
 
 constexpr uint32_t kNodeNoBox = 1u << 30;     // entry without a box test
@@ -95,6 +106,7 @@ public:
     void setCamera(const float* lookfrom, const float* lookat, const float* vup, float vfov, float aspect, float aperture,
                    float focus);
     void flatten();
+    void buildFastStructure();  // fast_bvh.cpp; called by flatten()
 
     Box3 objectBox(const Obj& o) const;
 

@@ -49,7 +49,8 @@ struct rt_context {
     unsigned int* queue = nullptr;
     unsigned long long* counters = nullptr;
     std::atomic<int> cancel{0};
-    unsigned long long sched_stats[12] = {0};  // from the last rt_count(): {executions, lanes} per operation
+    int force_ref = 0;
+    unsigned long long sched_stats[14] = {0};  // from the last rt_count(): {executions, lanes} per operation
 };
 
 namespace {
@@ -67,7 +68,7 @@ int fail(int code, const std::string& msg) {
 
 // Largest LDS footprint the staged-scene kernel is allowed to ask for.  Two such workgroups
 // still fit the 160 KiB of a CU.
-constexpr size_t kMaxLdsScene = 64 * 1024;
+constexpr size_t kMaxLdsScene = 72 * 1024;
 
 int envInt(const char* name, int dflt) {
     const char* v = std::getenv(name);
@@ -149,7 +150,7 @@ int launch(rt_context* ctx, rt::RenderArgs& a, bool count) {
     }
     HIP_TRY(hipMemsetAsync(ctx->queue, 0, 256, ctx->stream));
     a.queue = ctx->queue;
-    a.knob[0] = envInt("RT_BOX_KEEP", 24);
+    a.knob[0] = envInt("RT_BOX_KEEP", 8);
     a.knob[1] = envInt("RT_SHADE_MIN", 32);
     int wfThreads = envInt("RT_THREADS", 512);
     if (wfThreads != 256 && wfThreads != 512 && wfThreads != 1024) wfThreads = 512;
@@ -271,8 +272,15 @@ int rt_scene_flatten(rt_scene* s, rt_flat_info* info) {
         info->n_materials = (int)sc.materials.size();
         info->n_textures = (int)sc.textures.size();
         info->max_leaf = sc.flat.max_leaf;
-        info->fits_lds =
-            rt::ldsSceneBytes(info->n_nodes, info->n_prim_refs, info->n_spheres, info->n_triangles, info->n_materials) <= kMaxLdsScene;
+        rt::DevScene d{};
+        d.n_nodes = info->n_nodes;
+        d.n_prim_refs = info->n_prim_refs;
+        d.n_fast_nodes = (int)(sc.flat.fast_nodes.size() / 8);
+        d.n_fast_refs = (int)sc.flat.fast_refs.size();
+        d.n_spheres = info->n_spheres;
+        d.n_tris = info->n_triangles;
+        d.n_mats = info->n_materials;
+        info->fits_lds = rt::ldsSceneBytes(d) <= kMaxLdsScene;
     }
     return RT_OK;
 }
@@ -364,6 +372,13 @@ int rt_set_stream(rt_context* ctx, void* hip_stream) {
     return RT_OK;
 }
 
+int rt_set_reference_traversal(rt_context* ctx, int on) {
+    if (!ctx) return fail(RT_ERR_INVALID, "null context");
+    ctx->force_ref = on ? 1 : 0;
+    ctx->dsc.force_ref = ctx->force_ref;
+    return RT_OK;
+}
+
 int rt_upload_scene(rt_context* ctx, rt_scene* s) {
     if (!ctx || !s) return fail(RT_ERR_INVALID, "null handle");
     HIP_TRY(hipSetDevice(ctx->device));
@@ -428,6 +443,14 @@ int rt_upload_scene(rt_context* ctx, rt_scene* s) {
     std::memcpy(nodes.data(), sc.flat.nodes.data(), sc.flat.nodes.size() * 4);
     if ((rc = devUpload(ctx, nodes, &d.nodes))) return rc;
     if ((rc = devUpload(ctx, sc.flat.prim_refs, &d.prim_refs))) return rc;
+    std::vector<float4> fastNodes(sc.flat.fast_nodes.size() / 4);
+    std::memcpy(fastNodes.data(), sc.flat.fast_nodes.data(), sc.flat.fast_nodes.size() * 4);
+    if ((rc = devUpload(ctx, fastNodes, &d.fast_nodes))) return rc;
+    if ((rc = devUpload(ctx, sc.flat.fast_refs, &d.fast_refs))) return rc;
+    if ((rc = devUpload(ctx, sc.flat.sphere_ord, &d.sphere_ord))) return rc;
+    if ((rc = devUpload(ctx, sc.flat.tri_ord, &d.tri_ord))) return rc;
+    if ((rc = devUpload(ctx, sc.flat.prim_guard, &d.prim_guard))) return rc;
+    if ((rc = devUpload(ctx, sc.flat.node_outer, &d.node_outer))) return rc;
     if ((rc = devUpload(ctx, spheres, &d.spheres))) return rc;
     if ((rc = devUpload(ctx, sphereMat, &d.sphere_mat))) return rc;
     if ((rc = devUpload(ctx, triI, &d.tri_isect))) return rc;
@@ -439,13 +462,16 @@ int rt_upload_scene(rt_context* ctx, rt_scene* s) {
     if ((rc = devUpload(ctx, lut, &d.lut))) return rc;
     d.n_nodes = nNodes;
     d.n_prim_refs = (int)sc.flat.prim_refs.size();
+    d.n_fast_nodes = (int)(sc.flat.fast_nodes.size() / 8);
+    d.n_fast_refs = (int)sc.flat.fast_refs.size();
+    d.force_ref = ctx->force_ref;
     d.n_spheres = (int)sc.spheres.size();
     d.n_tris = (int)sc.triangles.size();
     d.n_mats = (int)sc.materials.size();
     std::memcpy(d.cam, &sc.camera, sizeof(float) * 22);
     std::memcpy(d.bg, sc.background, sizeof(float) * 3);
     ctx->dsc = d;
-    ctx->lds_need = rt::ldsSceneBytes(d.n_nodes, d.n_prim_refs, d.n_spheres, d.n_tris, d.n_mats);
+    ctx->lds_need = rt::ldsSceneBytes(d);
     ctx->use_lds = ctx->lds_need <= kMaxLdsScene && envInt("RT_LDS", 1) != 0;
     ctx->scene_loaded = true;
     return RT_OK;
@@ -682,7 +708,7 @@ int rt_count(rt_context* ctx, int first_sample, int n_samples, int max_depth, rt
         a.accum = scratch;
         rcl = launch(ctx, a, true);
     }
-    unsigned long long host[32] = {0};
+    unsigned long long host[32] = {0};  // 13 path counters, 7 x 2 scheduler pairs, fallbacks
     if (e == hipSuccess && rcl == RT_OK)
         e = hipMemcpyAsync(host, ctx->counters, sizeof host, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -702,13 +728,14 @@ int rt_count(rt_context* ctx, int first_sample, int n_samples, int max_depth, rt
     out->scatter_pbr = host[10];
     out->misses = host[11];
     out->depth_cutoffs = host[12];
+    out->fallbacks = host[27];
     std::memcpy(ctx->sched_stats, host + 13, sizeof ctx->sched_stats);
     return RT_OK;
 }
 
-int rt_sched_stats(rt_context* ctx, uint64_t* out12) {
-    if (!ctx || !out12) return fail(RT_ERR_INVALID, "bad arguments");
-    for (int i = 0; i < 12; i++) out12[i] = ctx->sched_stats[i];
+int rt_sched_stats(rt_context* ctx, uint64_t* out14) {
+    if (!ctx || !out14) return fail(RT_ERR_INVALID, "bad arguments");
+    for (int i = 0; i < 14; i++) out14[i] = ctx->sched_stats[i];
     return RT_OK;
 }
 

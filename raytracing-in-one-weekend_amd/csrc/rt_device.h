@@ -8,8 +8,17 @@ namespace rt {
 // Where each array of the flattened scene lives in HBM.  Everything is read-only during
 // a render and small enough for the cover scene to be staged whole into LDS.
 struct DevScene {
+    // reference-order arrays (the flatten step's output)
     const float4* nodes;      // 2 x float4 per entry: {min.xyz, skip|flags}, {max.xyz, first_ref}
     const uint32_t* prim_refs;
+    // search structure traversed first (same entry format, padded boxes) and its guard data
+    const float4* fast_nodes;
+    const uint32_t* fast_refs;
+    const int* sphere_ord;    // sphere id   -> position in prim_refs (the reference's visit order)
+    const int* tri_ord;       // triangle id -> position in prim_refs
+    const int* prim_guard;    // position in prim_refs -> innermost box-tested entry of `nodes` above it, or -1
+    const int* node_outer;    // entry of `nodes` -> next enclosing entry that must be checked too, or -1
+    // primitives and materials
     const float4* spheres;    // {c.xyz, r}
     const int* sphere_mat;
     const float4* tri_isect;  // 3 x float4 per triangle: {v0.xyz, -}, {edge1.xyz, -}, {edge2.xyz, -}
@@ -19,7 +28,8 @@ struct DevScene {
     const uint32_t* texels;   // all textures, RGBX8, one dword per texel
     const int4* tex_desc;     // {first texel, width, height, 0}
     const float* lut;         // 256-entry 8-bit -> float map
-    int n_nodes, n_prim_refs, n_spheres, n_tris, n_mats;
+    int n_nodes, n_prim_refs, n_fast_nodes, n_fast_refs, n_spheres, n_tris, n_mats;
+    int force_ref;            // 1: always walk `nodes` in the reference's order (diagnostics)
     float cam[22];            // origin, lowerLeftCorner, horizontal, vertical, u, v, w, lensRadius
     float bg[3];
 };
@@ -27,8 +37,8 @@ struct DevScene {
 struct RenderArgs {
     DevScene sc;
     float4* accum;        // tiled: [local tile][lane] -> {r, g, b, samples}
-    unsigned int* queue;  // next-tile counter for the persistent launch shape (may be null)
-    unsigned long long* counters;  // 13 path statistics (counting launches only)
+    unsigned int* queue;  // next-slot counter of the persistent launch shape (may be null)
+    unsigned long long* counters;  // path statistics (counting launches only)
     int width, height;
     int tiles_x, tiles_y;      // 8x8-pixel tiles
     int tiles_per_row_local;   // owned tiles per tile row = ceil(tiles_x / world)
@@ -41,12 +51,14 @@ struct RenderArgs {
 
 constexpr int kTile = 8;  // one wave64 = one 8x8 pixel tile
 
-// Bytes of LDS the staged scene tables need (nodes, leaf references, spheres, triangle
-// intersection records, per-primitive material indices, materials), each block 16-byte aligned.
-inline size_t ldsSceneBytes(int n_nodes, int n_refs, int n_spheres, int n_tris, int n_mats) {
+// Bytes of LDS the staged scene tables need, each block 16-byte aligned (order = stageScene()).
+inline size_t ldsSceneBytes(const DevScene& s) {
     auto al = [](size_t x) { return (x + 15) & ~size_t(15); };
-    return al((size_t)n_nodes * 32) + al((size_t)n_refs * 4) + al((size_t)n_spheres * 16) + al((size_t)n_tris * 48) +
-           al((size_t)n_spheres * 4) + al((size_t)n_tris * 4) + al((size_t)n_mats * 32);
+    return al((size_t)s.n_nodes * 32) + al((size_t)s.n_prim_refs * 4) + al((size_t)s.n_fast_nodes * 32) +
+           al((size_t)s.n_fast_refs * 4) + al((size_t)s.n_spheres * 16) + al((size_t)s.n_tris * 48) +
+           al((size_t)s.n_spheres * 4) + al((size_t)s.n_tris * 4) + al((size_t)s.n_mats * 32) +
+           al((size_t)s.n_spheres * 4) + al((size_t)s.n_tris * 4) + al((size_t)s.n_prim_refs * 4) +
+           al((size_t)s.n_nodes * 4);
 }
 
 }  // namespace rt

@@ -79,23 +79,31 @@ __device__ __forceinline__ V3 randomInUnitSphere(Rng& rng) {
 
 // Scene arrays as the traversal sees them: either straight from HBM/L2 or staged in LDS.
 struct SceneView {
-    const float4* nodes;
+    const float4* nodes;    // reference-order entries
     const uint32_t* refs;
+    const float4* fnodes;   // search structure traversed first
+    const uint32_t* frefs;
     const float4* spheres;
     const float4* tris;
     const int* sphere_mat;
     const int* tri_mat;
     const float4* materials;
+    const int* sphere_ord;
+    const int* tri_ord;
+    const int* prim_guard;
+    const int* node_outer;
 };
 
 __device__ __forceinline__ SceneView globalView(const DevScene& sc) {
-    return SceneView{sc.nodes, sc.prim_refs, sc.spheres, sc.tri_isect, sc.sphere_mat, sc.tri_mat, sc.materials};
+    return SceneView{sc.nodes,      sc.prim_refs, sc.fast_nodes, sc.fast_refs,  sc.spheres,    sc.tri_isect, sc.sphere_mat,
+                     sc.tri_mat,    sc.materials, sc.sphere_ord, sc.tri_ord,    sc.prim_guard, sc.node_outer};
 }
 
+constexpr int kNumStats = 14;
 struct Stats {
-    unsigned long long v[13];
+    unsigned long long v[kNumStats];
 };
-enum { C_SAMPLES, C_RAYS, C_NODE, C_SPHERE, C_TRI, C_HITS, C_LAMB, C_METAL, C_DIEL, C_LIGHT, C_PBR, C_MISS, C_CUTOFF };
+enum { C_SAMPLES, C_RAYS, C_NODE, C_SPHERE, C_TRI, C_HITS, C_LAMB, C_METAL, C_DIEL, C_LIGHT, C_PBR, C_MISS, C_CUTOFF, C_FALLBACK };
 
 struct Ray {
     V3 o, d;
@@ -125,58 +133,87 @@ __device__ __forceinline__ bool slabPass(const float4& n0, const float4& n1, con
     return !(tmax <= tmin);
 }
 
-// One primitive against the ray with the running closest hit as tMax.  A later primitive
-// wins a tie in t (`tMax < t` rejects, equality accepts), as in the reference.
+// Sphere::Hit / Triangle::Hit (R/src/Core/Hittable.h:228-255, 58-141) for one leaf reference:
+// true with the hit distance (and a triangle's barycentrics) if the primitive is hit within
+// [0.001, tMax].  `tMax < t` rejects, equality accepts, as in the reference.
 template <bool COUNT>
-__device__ __forceinline__ void primTest(const SceneView& sv, uint32_t ref, const Ray& r, float a, Hit& h, Stats* st) {
+__device__ __forceinline__ bool primRoot(const SceneView& sv, uint32_t ref, const Ray& r, float a, float tMax, float& tOut,
+                                         float& uOut, float& vOut, Stats* st) {
     const uint32_t id = ref & kRefId;
     if (ref & kRefTri) {
-        // Triangle::Hit, R/src/Core/Hittable.h:58-141 (edges are precomputed on the host with the
-        // same two subtractions)
+        // edges are precomputed on the host with the reference's two subtractions
         if (COUNT) st->v[C_TRI]++;
         const float4 q0 = sv.tris[3 * id], q1 = sv.tris[3 * id + 1], q2 = sv.tris[3 * id + 2];
         const V3 v0{q0.x, q0.y, q0.z}, e1{q1.x, q1.y, q1.z}, e2{q2.x, q2.y, q2.z};
         const float EPS = 1e-8f;
         V3 hh = cross(r.d, e2);
         float det = dot(e1, hh);
-        if (!(det > -EPS && det < EPS)) {
-            float f = 1.0f / det;
-            V3 s = r.o - v0;
-            float u = f * dot(s, hh);
-            if (!(u < 0.0f || u > 1.0f)) {
-                V3 q = cross(s, e1);
-                float v = f * dot(r.d, q);
-                if (!(v < 0.0f || u + v > 1.0f)) {
-                    float t = f * dot(e2, q);
-                    if (!(t < kTMin || h.t < t) && (t > EPS)) {
-                        h.t = t;
-                        h.ref = ref & ~kRefLast;
-                        h.bu = u;
-                        h.bv = v;
-                    }
-                }
-            }
-        }
-    } else {
-        // Sphere::Hit, R/src/Core/Hittable.h:228-255
-        if (COUNT) st->v[C_SPHERE]++;
-        const float4 s = sv.spheres[id];
-        V3 oc{r.o.x - s.x, r.o.y - s.y, r.o.z - s.z};
-        float halfB = dot(oc, r.d);
-        float c = dot(oc, oc) - s.w * s.w;
-        float disc = halfB * halfB - a * c;
-        if (!(disc < 0)) {
-            float sq = sqrtf(disc);
-            float root = (-halfB - sq) / a;
-            bool ok = true;
-            if (root < kTMin || h.t < root) {
-                root = (-halfB + sq) / a;
-                if (root < kTMin || h.t < root) ok = false;
-            }
-            if (ok) {
-                h.t = root;
-                h.ref = ref & ~kRefLast;
-            }
+        if (det > -EPS && det < EPS) return false;
+        float f = 1.0f / det;
+        V3 s = r.o - v0;
+        float u = f * dot(s, hh);
+        if (u < 0.0f || u > 1.0f) return false;
+        V3 q = cross(s, e1);
+        float v = f * dot(r.d, q);
+        if (v < 0.0f || u + v > 1.0f) return false;
+        float t = f * dot(e2, q);
+        if (t < kTMin || tMax < t) return false;
+        if (!(t > EPS)) return false;
+        tOut = t;
+        uOut = u;
+        vOut = v;
+        return true;
+    }
+    if (COUNT) st->v[C_SPHERE]++;
+    const float4 s = sv.spheres[id];
+    V3 oc{r.o.x - s.x, r.o.y - s.y, r.o.z - s.z};
+    float halfB = dot(oc, r.d);
+    float c = dot(oc, oc) - s.w * s.w;
+    float disc = halfB * halfB - a * c;
+    if (disc < 0) return false;
+    float sq = sqrtf(disc);
+    float root = (-halfB - sq) / a;
+    if (root < kTMin || tMax < root) {
+        root = (-halfB + sq) / a;
+        if (root < kTMin || tMax < root) return false;
+    }
+    tOut = root;
+    return true;
+}
+
+// The reference's own update rule: primitives arrive in its visit order and each one is
+// tested against the running closest hit.
+template <bool COUNT>
+__device__ __forceinline__ void primRef(const SceneView& sv, uint32_t ref, const Ray& r, float a, Hit& h, Stats* st) {
+    float t, u = h.bu, v = h.bv;
+    if (primRoot<COUNT>(sv, ref, r, a, h.t, t, u, v, st)) {
+        h.t = t;
+        h.ref = ref & ~kRefLast;
+        h.bu = u;
+        h.bv = v;
+    }
+}
+
+__device__ __forceinline__ int refOrder(const SceneView& sv, uint32_t ref) {
+    return (ref & kRefTri) ? sv.tri_ord[ref & kRefId] : sv.sphere_ord[ref & kRefId];
+}
+
+// Update rule for primitives that arrive in any order: smallest hit distance wins, and of two
+// primitives with exactly the same distance the one the reference visits later (the one its
+// `tMax < t` test lets overwrite the other).  A NaN distance cannot be ordered: `bad` is set and
+// the ray is traced again in the reference's order.
+template <bool COUNT>
+__device__ __forceinline__ void primAnyOrder(const SceneView& sv, uint32_t ref, const Ray& r, float a, Hit& h, bool& bad,
+                                             Stats* st) {
+    float t, u = 0.0f, v = 0.0f;
+    if (primRoot<COUNT>(sv, ref, r, a, __builtin_inff(), t, u, v, st)) {
+        if (t != t) {
+            bad = true;
+        } else if (h.ref == kNoHit || t < h.t || (t == h.t && refOrder(sv, ref) > refOrder(sv, h.ref))) {
+            h.t = t;
+            h.ref = ref & ~kRefLast;
+            h.bu = u;
+            h.bv = v;
         }
     }
 }
@@ -186,14 +223,9 @@ __device__ __forceinline__ void primTest(const SceneView& sv, uint32_t ref, cons
 // one, R/src/AccelerationStructures/Bvh.h:84-85, which is the running closest hit); on a miss
 // jump to `skip`, else test the entry's leaf run and go to i + 1.
 template <bool COUNT>
-__device__ __forceinline__ Hit traverse(const SceneView& sv, int n_nodes, const Ray& r, Stats* st) {
-    Hit h;
-    h.t = __builtin_inff();
-    h.ref = kNoHit;
-    h.bu = 0.0f;
-    h.bv = 0.0f;
-    const float invx = 1.0f / r.d.x, invy = 1.0f / r.d.y, invz = 1.0f / r.d.z;
-    const float a = dot(r.d, r.d);
+__device__ __forceinline__ Hit traverseRef(const SceneView& sv, int n_nodes, const Ray& r, float invx, float invy, float invz,
+                                           float a, Stats* st) {
+    Hit h{__builtin_inff(), kNoHit, 0.0f, 0.0f};
     int idx = 0;
     while (idx < n_nodes) {
         const float4 n0 = sv.nodes[2 * idx], n1 = sv.nodes[2 * idx + 1];
@@ -210,7 +242,7 @@ __device__ __forceinline__ Hit traverse(const SceneView& sv, int n_nodes, const 
                 uint32_t ref;
                 do {
                     ref = sv.refs[p++];
-                    primTest<COUNT>(sv, ref, r, a, h, st);
+                    primRef<COUNT>(sv, ref, r, a, h, st);
                 } while (!(ref & kRefLast));
             }
             idx = idx + 1;
@@ -219,6 +251,68 @@ __device__ __forceinline__ Hit traverse(const SceneView& sv, int n_nodes, const 
         }
     }
     return h;
+}
+
+// The same walk over the search structure: tighter tree, padded boxes, order-independent update.
+template <bool COUNT>
+__device__ __forceinline__ Hit traverseFast(const SceneView& sv, int n_nodes, const Ray& r, float invx, float invy, float invz,
+                                            float a, bool& bad, Stats* st) {
+    Hit h{__builtin_inff(), kNoHit, 0.0f, 0.0f};
+    int idx = 0;
+    while (idx < n_nodes) {
+        const float4 n0 = sv.fnodes[2 * idx], n1 = sv.fnodes[2 * idx + 1];
+        const int first = (int)fbits(n1.w);
+        if (COUNT) st->v[C_NODE]++;
+        if (slabPass(n0, n1, r, invx, invy, invz, h.t)) {
+            if (first >= 0) {
+                int p = first;
+                uint32_t ref;
+                do {
+                    ref = sv.frefs[p++];
+                    primAnyOrder<COUNT>(sv, ref, r, a, h, bad, st);
+                } while (!(ref & kRefLast));
+            }
+            idx = idx + 1;
+        } else {
+            idx = (int)(fbits(n0.w) & kSkipMask);
+        }
+    }
+    return h;
+}
+
+// The condition under which the reference's walk returns exactly the hit found by the search
+// structure: the innermost reference box above the winner, and every enclosing box that does
+// not contain it, pass the reference's slab test with tMax = the winner's distance.
+template <bool COUNT>
+__device__ __forceinline__ bool guardsPass(const SceneView& sv, const Ray& r, float invx, float invy, float invz, const Hit& h,
+                                           Stats* st) {
+    int g = sv.prim_guard[refOrder(sv, h.ref)];
+    while (g >= 0) {
+        if (COUNT) st->v[C_NODE]++;
+        if (!slabPass(sv.nodes[2 * g], sv.nodes[2 * g + 1], r, invx, invy, invz, h.t)) return false;
+        g = sv.node_outer[g];
+    }
+    return true;
+}
+
+__device__ __forceinline__ bool finite3(float x, float y, float z) {
+    const float inf = __builtin_inff();
+    return fabsf(x) < inf && fabsf(y) < inf && fabsf(z) < inf;
+}
+
+// mWorld.Hit(r, 0.001f, infinity, rec) (R/src/Core/Raytracer.cpp:10): search structure first,
+// the reference's own walk when its answer cannot be vouched for.
+template <bool COUNT>
+__device__ __forceinline__ Hit closestHit(const DevScene& sc, const SceneView& sv, const Ray& r, Stats* st) {
+    const float invx = 1.0f / r.d.x, invy = 1.0f / r.d.y, invz = 1.0f / r.d.z;
+    const float a = dot(r.d, r.d);
+    if (!sc.force_ref && finite3(invx, invy, invz)) {
+        bool bad = false;
+        Hit h = traverseFast<COUNT>(sv, sc.n_fast_nodes, r, invx, invy, invz, a, bad, st);
+        if (!bad && (h.ref == kNoHit || guardsPass<COUNT>(sv, r, invx, invy, invz, h, st))) return h;
+        if (COUNT) st->v[C_FALLBACK]++;
+    }
+    return traverseRef<COUNT>(sv, sc.n_nodes, r, invx, invy, invz, a, st);
 }
 
 struct Surface {
@@ -397,7 +491,7 @@ __device__ __forceinline__ V3 rayColor(const DevScene& sc, const SceneView& sv, 
             return throughput * V3{0.0f, 0.0f, 0.0f};
         }
         if (COUNT) st->v[C_RAYS]++;
-        Hit h = traverse<COUNT>(sv, sc.n_nodes, r, st);
+        Hit h = closestHit<COUNT>(sc, sv, r, st);
         if (h.ref == kNoHit) {
             if (COUNT) st->v[C_MISS]++;
             return throughput * V3{sc.bg[0], sc.bg[1], sc.bg[2]};
@@ -415,36 +509,39 @@ __device__ __forceinline__ V3 rayColor(const DevScene& sc, const SceneView& sv, 
 
 extern __shared__ float4 rt_lds[];
 
-// Stages the traversal and shading tables (nodes, leaf references, spheres, triangle
-// intersection records, material indices, materials) into LDS and returns views into it
-// (layout = ldsSceneBytes()).
+// Stages the scene tables into LDS and returns views into it (layout = ldsSceneBytes()).
 __device__ __forceinline__ SceneView stageScene(const DevScene& sc) {
-    auto al = [](int x) { return (x + 15) & ~15; };
     char* base = reinterpret_cast<char*>(rt_lds);
     int off = 0;
-    float4* nodes = reinterpret_cast<float4*>(base + off);
-    off += al(sc.n_nodes * 32);
-    uint32_t* refs = reinterpret_cast<uint32_t*>(base + off);
-    off += al(sc.n_prim_refs * 4);
-    float4* spheres = reinterpret_cast<float4*>(base + off);
-    off += al(sc.n_spheres * 16);
-    float4* tris = reinterpret_cast<float4*>(base + off);
-    off += al(sc.n_tris * 48);
-    int* smat = reinterpret_cast<int*>(base + off);
-    off += al(sc.n_spheres * 4);
-    int* tmat = reinterpret_cast<int*>(base + off);
-    off += al(sc.n_tris * 4);
-    float4* mats = reinterpret_cast<float4*>(base + off);
     const int tid = threadIdx.x, nt = blockDim.x;
-    for (int i = tid; i < sc.n_nodes * 2; i += nt) nodes[i] = sc.nodes[i];
-    for (int i = tid; i < sc.n_prim_refs; i += nt) refs[i] = sc.prim_refs[i];
-    for (int i = tid; i < sc.n_spheres; i += nt) spheres[i] = sc.spheres[i];
-    for (int i = tid; i < sc.n_tris * 3; i += nt) tris[i] = sc.tri_isect[i];
-    for (int i = tid; i < sc.n_spheres; i += nt) smat[i] = sc.sphere_mat[i];
-    for (int i = tid; i < sc.n_tris; i += nt) tmat[i] = sc.tri_mat[i];
-    for (int i = tid; i < sc.n_mats * 2; i += nt) mats[i] = sc.materials[i];
+    auto take16 = [&](const float4* src, int n) {
+        float4* dst = reinterpret_cast<float4*>(base + off);
+        off += (n * 16 + 15) & ~15;
+        for (int i = tid; i < n; i += nt) dst[i] = src[i];
+        return dst;
+    };
+    auto take4 = [&](const uint32_t* src, int n) {
+        uint32_t* dst = reinterpret_cast<uint32_t*>(base + off);
+        off += (n * 4 + 15) & ~15;
+        for (int i = tid; i < n; i += nt) dst[i] = src[i];
+        return dst;
+    };
+    SceneView v;
+    v.nodes = take16(sc.nodes, sc.n_nodes * 2);
+    v.refs = take4(sc.prim_refs, sc.n_prim_refs);
+    v.fnodes = take16(sc.fast_nodes, sc.n_fast_nodes * 2);
+    v.frefs = take4(sc.fast_refs, sc.n_fast_refs);
+    v.spheres = take16(sc.spheres, sc.n_spheres);
+    v.tris = take16(sc.tri_isect, sc.n_tris * 3);
+    v.sphere_mat = reinterpret_cast<const int*>(take4(reinterpret_cast<const uint32_t*>(sc.sphere_mat), sc.n_spheres));
+    v.tri_mat = reinterpret_cast<const int*>(take4(reinterpret_cast<const uint32_t*>(sc.tri_mat), sc.n_tris));
+    v.materials = take16(sc.materials, sc.n_mats * 2);
+    v.sphere_ord = reinterpret_cast<const int*>(take4(reinterpret_cast<const uint32_t*>(sc.sphere_ord), sc.n_spheres));
+    v.tri_ord = reinterpret_cast<const int*>(take4(reinterpret_cast<const uint32_t*>(sc.tri_ord), sc.n_tris));
+    v.prim_guard = reinterpret_cast<const int*>(take4(reinterpret_cast<const uint32_t*>(sc.prim_guard), sc.n_prim_refs));
+    v.node_outer = reinterpret_cast<const int*>(take4(reinterpret_cast<const uint32_t*>(sc.node_outer), sc.n_nodes));
     __syncthreads();
-    return SceneView{nodes, refs, spheres, tris, smat, tmat, mats};
+    return v;
 }
 
 // Pixel loops of RaytracerNormal::Run (R/src/Core/Raytracer.cpp:76-93) for the tiles this
@@ -465,7 +562,7 @@ __global__ void __launch_bounds__(256) renderKernel(RenderArgs a) {
     const int nWaves = gridDim.x * wavesPerBlock;
     Stats st;
     if (COUNT)
-        for (int i = 0; i < 13; i++) st.v[i] = 0;
+        for (int i = 0; i < kNumStats; i++) st.v[i] = 0;
 
     int tile = wave;
     if (a.queue) {
@@ -505,10 +602,11 @@ __global__ void __launch_bounds__(256) renderKernel(RenderArgs a) {
         }
     }
     if (COUNT) {
-        for (int i = 0; i < 13; i++) {
+        for (int i = 0; i < kNumStats; i++) {
             unsigned long long v = st.v[i];
             for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-            if (lane == 0 && v) atomicAdd(&a.counters[i], v);
+            // the scheduler statistics sit between the 13 path counters and the fallback count
+            if (lane == 0 && v) atomicAdd(&a.counters[i < 13 ? i : 27], v);
         }
     }
 }
@@ -539,14 +637,14 @@ __global__ void __launch_bounds__(1024) renderWavefront(RenderArgs a) {
         sv = globalView(sc);
     }
     const int lane = threadIdx.x & 63;
-    const int nNodes = sc.n_nodes;
+    const int nNodesRef = sc.n_nodes, nNodesFast = sc.n_fast_nodes;
     const int nSlots = a.n_local_tiles * 64;
     const int sEnd = a.first_sample + a.n_samples;
     const int boxKeep = a.knob[0];    // keep running BOX steps while at least this many lanes want one
     const int shadeMin = a.knob[1];   // run SHADE / NEWPATH early once this many lanes wait for it
     Stats st;
     if (COUNT)
-        for (int i = 0; i < 13; i++) st.v[i] = 0;
+        for (int i = 0; i < kNumStats; i++) st.v[i] = 0;
 
     int op = OP_NEWPIXEL;
     int q = 0, px = 0, py = 0, s = 0, depth = 0, idx = 0, p = 0;
@@ -555,6 +653,9 @@ __global__ void __launch_bounds__(1024) renderWavefront(RenderArgs a) {
     Ray r{{0.f, 0.f, 0.f}, {0.f, 0.f, 1.f}};
     float invx = 0.f, invy = 0.f, invz = 0.f, aa = 1.f;
     Hit h{0.f, kNoHit, 0.f, 0.f};
+    // 0: the lane walks the search structure; 1: it walks the reference-order array (diagnostic
+    // setting, zero direction component, or a re-trace after a failed guard test / NaN distance)
+    int mode = 0;
 
     // wave-local pool of pixel slots pulled from the launch-wide queue 64 at a time
     int poolNext = 0, poolEnd = 0;
@@ -569,7 +670,16 @@ __global__ void __launch_bounds__(1024) renderWavefront(RenderArgs a) {
         h.ref = kNoHit;
         idx = 0;
         op = OP_BOX;
+        mode = (sc.force_ref || !finite3(invx, invy, invz)) ? 1 : 0;
         if (COUNT) st.v[C_RAYS]++;
+    };
+    auto retraceInReferenceOrder = [&]() {
+        h.t = __builtin_inff();
+        h.ref = kNoHit;
+        idx = 0;
+        op = OP_BOX;
+        mode = 1;
+        if (COUNT) st.v[C_FALLBACK]++;
     };
     auto endPath = [&](V3 terminal) {
         V3 c = thr * terminal;
@@ -618,7 +728,9 @@ __global__ void __launch_bounds__(1024) renderWavefront(RenderArgs a) {
                     schedLanes[5] += popc64(__ballot(op == OP_BOX));
                 }
                 if (op == OP_BOX) {
-                    const float4 n0 = sv.nodes[2 * idx], n1 = sv.nodes[2 * idx + 1];
+                    const float4* nd = mode ? sv.nodes : sv.fnodes;
+                    const int nNodes = mode ? nNodesRef : nNodesFast;
+                    const float4 n0 = nd[2 * idx], n1 = nd[2 * idx + 1];
                     const uint32_t w3 = fbits(n0.w);
                     const int first = (int)fbits(n1.w);
                     // the box is tested even for list entries (whose box words are zero) so that
@@ -641,11 +753,18 @@ __global__ void __launch_bounds__(1024) renderWavefront(RenderArgs a) {
             } while (popc64(__ballot(op == OP_BOX)) >= keep && keep > 0);
         } else if (chosen == OP_PRIM) {
             if (op == OP_PRIM) {
-                const uint32_t ref = sv.refs[p];
-                primTest<COUNT>(sv, ref, r, aa, h, &st);
-                if (ref & kRefLast) {
+                const uint32_t ref = (mode ? sv.refs : sv.frefs)[p];
+                bool bad = false;
+                if (mode) {
+                    primRef<COUNT>(sv, ref, r, aa, h, &st);
+                } else {
+                    primAnyOrder<COUNT>(sv, ref, r, aa, h, bad, &st);
+                }
+                if (bad) {
+                    retraceInReferenceOrder();
+                } else if (ref & kRefLast) {
                     idx += 1;
-                    op = idx < nNodes ? OP_BOX : OP_SHADE;
+                    op = idx < (mode ? nNodesRef : nNodesFast) ? OP_BOX : OP_SHADE;
                 } else {
                     p += 1;
                 }
@@ -655,6 +774,8 @@ __global__ void __launch_bounds__(1024) renderWavefront(RenderArgs a) {
                 if (h.ref == kNoHit) {
                     if (COUNT) st.v[C_MISS]++;
                     endPath(V3{sc.bg[0], sc.bg[1], sc.bg[2]});
+                } else if (mode == 0 && !guardsPass<COUNT>(sv, r, invx, invy, invz, h, &st)) {
+                    retraceInReferenceOrder();
                 } else {
                     if (COUNT) st.v[C_HITS]++;
                     Surface sf = surfaceAt(sc, sv, r, h);
@@ -746,10 +867,11 @@ __global__ void __launch_bounds__(1024) renderWavefront(RenderArgs a) {
         }
     }
     if (COUNT) {
-        for (int i = 0; i < 13; i++) {
+        for (int i = 0; i < kNumStats; i++) {
             unsigned long long v = st.v[i];
             for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-            if (lane == 0 && v) atomicAdd(&a.counters[i], v);
+            // the scheduler statistics sit between the 13 path counters and the fallback count
+            if (lane == 0 && v) atomicAdd(&a.counters[i < 13 ? i : 27], v);
         }
     }
 }
@@ -763,7 +885,7 @@ __global__ void __launch_bounds__(256) traceKernel(DevScene sc, int n, const flo
     Ray r;
     r.o = {rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]};
     r.d = {rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]};
-    Hit h = traverse<false>(sv, sc.n_nodes, r, nullptr);
+    Hit h = closestHit<false>(sc, sv, r, nullptr);
     if (h.ref == kNoHit) {
         kind[i] = -1;
         id[i] = -1;

@@ -271,13 +271,45 @@ def test_render_lambertian_mesh_without_roughness(rt, orc, scenes, gpu_ctx):
 def test_path_counters_equal_the_oracle(rt, orc, scenes, gpu_ctx):
     w, h, spp = 120, 68, 2
     a, b = both(rt, orc, lambda s: scenes.cover_scene(s, w, h))
+    _, _, want = b.render(w, h, 0, spp, 50, rng_mode=1, order=1, threads=8, want_counters=True)
+    # walking the reference-order array: every counter, node and primitive tests included
+    gpu_ctx.set_reference_traversal(True)
     gpu_ctx.upload_scene(a)
     gpu_ctx.set_target(w, h)
     got = gpu_ctx.count(0, spp, 50)
-    _, _, want = b.render(w, h, 0, spp, 50, rng_mode=1, order=1, threads=8, want_counters=True)
+    assert got.pop("fallbacks") == 0
     assert got == want
     assert got["samples"] == w * h * spp and got["rays"] >= got["samples"]
     assert got["hits"] + got["misses"] == got["rays"]
+    # default traversal (search structure first): same paths, far fewer box tests
+    gpu_ctx.set_reference_traversal(False)
+    gpu_ctx.upload_scene(a)
+    fast = gpu_ctx.count(0, spp, 50)
+    for k in ("samples", "rays", "hits", "misses", "depth_cutoffs", "scatter_lambertian", "scatter_metal",
+              "scatter_dielectric", "scatter_light", "scatter_pbr"):
+        assert fast[k] == want[k], k
+    assert fast["node_tests"] < 0.7 * want["node_tests"]
+    assert fast["fallbacks"] < 1e-3 * fast["rays"]
+
+
+def test_reference_order_traversal_gives_identical_results(rt, orc, scenes, gpu_ctx):
+    """The diagnostic switch that makes every ray walk the reference-order array: same hits,
+    same image bits as the default (search structure + guard test + re-trace)."""
+    w, h, spp = 200, 112, 2
+    a, b = both(rt, orc, lambda s: scenes.cover_scene(s, w, h))
+    rays = rays_cover(30000, 11)
+    images, hits = [], []
+    for on in (True, False):
+        gpu_ctx.set_reference_traversal(on)
+        gpu_ctx.upload_scene(a)
+        hits.append(gpu_ctx.trace(rays))
+        images.append(render_gpu(gpu_ctx, w, h, 0, spp))
+    gpu_ctx.set_reference_traversal(False)
+    for x, y in zip(hits[0], hits[1]):
+        assert np.array_equal(bits(x), bits(y)) if x.dtype == np.float32 else np.array_equal(x, y)
+    assert np.array_equal(bits(images[0]), bits(images[1]))
+    want, _, _ = b.render(w, h, 0, spp, 50, rng_mode=1, order=1, threads=8)
+    assert np.array_equal(bits(images[1][..., :3]), bits(want[..., :3]))
 
 
 def test_two_rank_partition_gathers_to_the_single_rank_image(rt, scenes, tiling, gpu_ctx):
