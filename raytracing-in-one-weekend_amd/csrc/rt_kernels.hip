@@ -656,10 +656,6 @@ __global__ void __launch_bounds__(1024) renderWavefront(RenderArgs a) {
     // 0: the lane walks the search structure; 1: it walks the reference-order array (diagnostic
     // setting, zero direction component, or a re-trace after a failed guard test / NaN distance)
     int mode = 0;
-    // 0: nothing pending; 1 / 2: the lane is in OP_SHADE waiting for an accepted unit-sphere vector
-    // (1: direction = base + unit vector, 2: direction = base + scale * vector, kept only if it
-    // leaves the surface); 3: the lane is in OP_NEWPATH waiting for an accepted lens sample
-    int pend = 0;
 
     // wave-local pool of pixel slots pulled from the launch-wide queue 64 at a time
     int poolNext = 0, poolEnd = 0;
@@ -690,16 +686,6 @@ __global__ void __launch_bounds__(1024) renderWavefront(RenderArgs a) {
         sum = sum + c;
         s += 1;
         op = OP_NEWPATH;
-    };
-    // the scattered ray is in r: rayColor(scattered, depth - 1), R/src/Core/Raytracer.cpp:19,7-8
-    auto bounce = [&]() {
-        depth -= 1;
-        if (depth <= 0) {
-            if (COUNT) st.v[C_CUTOFF]++;
-            endPath(V3{0.0f, 0.0f, 0.0f});
-        } else {
-            startRay();
-        }
     };
 
     for (;;) {
@@ -784,131 +770,51 @@ __global__ void __launch_bounds__(1024) renderWavefront(RenderArgs a) {
                 }
             }
         } else if (chosen == OP_SHADE) {
-            // rayColor after the world hit test (R/src/Core/Raytracer.cpp:10-19).  A lane that has
-            // to draw a vector in the unit sphere makes ONE attempt per execution and stays in this
-            // operation until an attempt is accepted, so a lane that needs five attempts does not
-            // hold up the others.
             if (op == OP_SHADE) {
-                if (pend == 0) {
-                    if (h.ref == kNoHit) {
-                        if (COUNT) st.v[C_MISS]++;
-                        endPath(V3{sc.bg[0], sc.bg[1], sc.bg[2]});
-                    } else if (mode == 0 && !guardsPass<COUNT>(sv, r, invx, invy, invz, h, &st)) {
-                        retraceInReferenceOrder();
+                if (h.ref == kNoHit) {
+                    if (COUNT) st.v[C_MISS]++;
+                    endPath(V3{sc.bg[0], sc.bg[1], sc.bg[2]});
+                } else if (mode == 0 && !guardsPass<COUNT>(sv, r, invx, invy, invz, h, &st)) {
+                    retraceInReferenceOrder();
+                } else {
+                    if (COUNT) st.v[C_HITS]++;
+                    Surface sf = surfaceAt(sc, sv, r, h);
+                    Ray out;
+                    V3 atten, emit;
+                    if (!scatter<COUNT>(sc, sv, r, sf, rng, out, atten, emit, &st)) {
+                        endPath(emit);
                     } else {
-                        if (COUNT) st.v[C_HITS]++;
-                        const Surface sf = surfaceAt(sc, sv, r, h);
-                        const float4 m0 = sv.materials[2 * sf.mat], m1 = sv.materials[2 * sf.mat + 1];
-                        const int kind = (int)fbits(m1.x);
-                        if (kind == 2) {  // Dielectric needs one plain draw only: finished here
-                            Ray out;
-                            V3 atten, emit;
-                            scatter<COUNT>(sc, sv, r, sf, rng, out, atten, emit, &st);
-                            thr = thr * atten;
-                            r = out;
-                            bounce();
-                        } else if (kind == 3) {  // DiffuseLight, Material.h:103-110
-                            if (COUNT) st.v[C_LIGHT]++;
-                            endPath(V3{m0.x, m0.y, m0.z});
-                        } else {
-                            // the part of Lambertian / Metal / PBR scatter (Material.h:27-35,49-52,142-158)
-                            // that precedes the random vector
-                            V3 atten{m0.x, m0.y, m0.z};
-                            bool mirror = kind == 1;
-                            V3 scale{m0.w, m0.w, m0.w};
-                            if (kind == 0) {
-                                if (COUNT) st.v[C_LAMB]++;
-                            } else if (kind == 1) {
-                                if (COUNT) st.v[C_METAL]++;
-                            } else {
-                                if (COUNT) st.v[C_PBR]++;
-                                const int texD = (int)fbits(m1.y), texR = (int)fbits(m1.z);
-                                atten = textureAt(sc, texD, sf.u, sf.v);
-                                mirror = texR >= 0;
-                                if (mirror) scale = textureAt(sc, texR, sf.u, sf.v);
-                            }
-                            // attenuation is applied now; if the scattered ray is later rejected the
-                            // path ends with zero radiance either way
-                            thr = thr * atten;
-                            const V3 base = mirror ? reflect(normalize(r.d), sf.n) : sf.n;
-                            // while the lane waits for an accepted vector: r.o = hit point, r.d = base
-                            // direction, (invx, invy, invz) = shading normal, (h.t, h.bu, h.bv) = scale
-                            r.o = sf.p;
-                            r.d = base;
-                            invx = sf.n.x;
-                            invy = sf.n.y;
-                            invz = sf.n.z;
-                            h.t = scale.x;
-                            h.bu = scale.y;
-                            h.bv = scale.z;
-                            pend = mirror ? 2 : 1;
-                        }
-                    }
-                }
-                if (op == OP_SHADE && pend != 0) {
-                    // one attempt of randomVecInUnitSphere (R/src/Core/RTWeekend.cpp:3-12; z, y, x)
-                    const float z = rng.next(-1.0f, 1.0f), y = rng.next(-1.0f, 1.0f), x = rng.next(-1.0f, 1.0f);
-                    const V3 v{x, y, z};
-                    if (!(dot(v, v) >= 1.0f)) {
-                        const V3 n{invx, invy, invz};
-                        const bool mirror = pend == 2;
-                        pend = 0;
-                        if (!mirror) {
-                            V3 dir = r.d + normalize(v);
-                            if (((double)fabsf(dir.x) < 1e-8) && ((double)fabsf(dir.y) < 1e-8) && ((double)fabsf(dir.z) < 1e-8))
-                                dir = n;
-                            r.d = dir;
-                            bounce();
-                        } else {
-                            const V3 scale{h.t, h.bu, h.bv};
-                            r.d = r.d + scale * v;
-                            if (dot(r.d, n) > 0) {
-                                bounce();
-                            } else {
-                                endPath(V3{0.0f, 0.0f, 0.0f});
-                            }
-                        }
-                    }
-                }
-            }
-        } else if (chosen == OP_NEWPATH) {
-            // next sample of the pixel (R/src/Core/Raytracer.cpp:84-89).  The lens sample is drawn by
-            // rejection, one attempt per execution (randomInUnitDisk, R/src/Core/RTWeekend.cpp:29-37;
-            // y before x), followed by Camera::GetRay (R/src/Core/Camera.h:27-33).
-            if (op == OP_NEWPATH) {
-                if (pend == 0) {
-                    if (s >= sEnd) {
-                        a.accum[q] = make_float4(sum.x, sum.y, sum.z, (float)sEnd);
-                        op = OP_NEWPIXEL;
-                    } else {
-                        rng.init((uint32_t)px, (uint32_t)py, s);
-                        if (COUNT) st.v[C_SAMPLES]++;
-                        // u is drawn before v (Raytracer.cpp:86-87); kept in (h.bu, h.bv) meanwhile
-                        h.bu = ((float)px + rng.next()) / (float)(a.width - 1);
-                        h.bv = ((float)py + rng.next()) / (float)(a.height - 1);
-                        thr = V3{1.0f, 1.0f, 1.0f};
-                        depth = a.max_depth;
-                        pend = 3;
-                    }
-                }
-                if (op == OP_NEWPATH && pend == 3) {
-                    const float dy = rng.next(-1.0f, 1.0f), dx = rng.next(-1.0f, 1.0f);
-                    if (!((dx * dx + dy * dy) + 0.0f * 0.0f >= 1)) {
-                        pend = 0;
-                        const float* c = sc.cam;
-                        const float lr = c[21];
-                        const float rdx = lr * dx, rdy = lr * dy;
-                        const V3 org{c[0], c[1], c[2]}, llc{c[3], c[4], c[5]}, hor{c[6], c[7], c[8]}, ver{c[9], c[10], c[11]};
-                        const V3 cu{c[12], c[13], c[14]}, cv{c[15], c[16], c[17]};
-                        const V3 offset = cu * rdx + cv * rdy;
-                        r.o = org + offset;
-                        r.d = llc + h.bu * hor + h.bv * ver - org - offset;
+                        thr = thr * atten;
+                        r = out;
+                        depth -= 1;
                         if (depth <= 0) {
                             if (COUNT) st.v[C_CUTOFF]++;
                             endPath(V3{0.0f, 0.0f, 0.0f});
                         } else {
                             startRay();
                         }
+                    }
+                }
+            }
+        } else if (chosen == OP_NEWPATH) {
+            if (op == OP_NEWPATH) {
+                if (s >= sEnd) {
+                    a.accum[q] = make_float4(sum.x, sum.y, sum.z, (float)sEnd);
+                    op = OP_NEWPIXEL;
+                } else {
+                    rng.init((uint32_t)px, (uint32_t)py, s);
+                    if (COUNT) st.v[C_SAMPLES]++;
+                    // u is drawn before v (R/src/Core/Raytracer.cpp:86-87)
+                    float u = ((float)px + rng.next()) / (float)(a.width - 1);
+                    float v = ((float)py + rng.next()) / (float)(a.height - 1);
+                    r = cameraRay(sc, u, v, rng);
+                    thr = V3{1.0f, 1.0f, 1.0f};
+                    depth = a.max_depth;
+                    if (depth <= 0) {
+                        if (COUNT) st.v[C_CUTOFF]++;
+                        endPath(V3{0.0f, 0.0f, 0.0f});
+                    } else {
+                        startRay();
                     }
                 }
             }
