@@ -24,7 +24,6 @@
 // monotonicity argument).
 #include <algorithm>
 #include <cmath>
-#include <cstdlib>
 #include <cstring>
 #include <limits>
 
@@ -60,10 +59,7 @@ struct Builder {
     std::vector<uint32_t>& nodes;
     std::vector<uint32_t>& refs;
     static constexpr int kBins = 16;
-    int kMaxLeaf = 2;
-    // per entry: the child on the low side of the split plane, the one on the high side
-    // (-1 for leaves) and the split axis (-1: no plane, children in build order)
-    std::vector<int> lowChild, highChild, splitAxis;
+    static constexpr int kMaxLeaf = 2;
 
     int newEntry(const float* mn, const float* mx) {
         int idx = (int)(nodes.size() / 8);
@@ -73,7 +69,7 @@ struct Builder {
         return idx;
     }
 
-    int build(size_t start, size_t end) {
+    void build(size_t start, size_t end) {
         float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
         float cmn[3] = {INFINITY, INFINITY, INFINITY}, cmx[3] = {-INFINITY, -INFINITY, -INFINITY};
         for (size_t i = start; i < end; i++) {
@@ -86,10 +82,6 @@ struct Builder {
             }
         }
         const int e = newEntry(mn, mx);
-        lowChild.push_back(-1);
-        highChild.push_back(-1);
-        splitAxis.push_back(-1);
-        int axisUsed = -1;
         const size_t n = end - start;
         size_t mid = 0;
         bool split = n > (size_t)kMaxLeaf;
@@ -162,11 +154,7 @@ struct Builder {
                     return b <= bestBin;
                 });
                 mid = (size_t)(it - prims.begin());
-                axisUsed = bestAxis;
-                if (mid == start || mid == end) {
-                    mid = start + n / 2;
-                    axisUsed = -1;
-                }
+                if (mid == start || mid == end) mid = start + n / 2;
             }
         }
         if (!split) {
@@ -185,46 +173,14 @@ struct Builder {
                     }
                 return area(lo, hi);
             };
-            bool lowFirst = true;
             if (rangeArea(start, mid) > rangeArea(mid, end)) {
                 std::rotate(prims.begin() + start, prims.begin() + mid, prims.begin() + end);
                 mid = start + (end - mid);
-                lowFirst = false;
             }
-            const int c0 = build(start, mid);
-            const int c1 = build(mid, end);
-            lowChild[e] = lowFirst ? c0 : c1;
-            highChild[e] = lowFirst ? c1 : c0;
-            splitAxis[e] = axisUsed;
+            build(start, mid);
+            build(mid, end);
         }
         nodes[(size_t)e * 8 + 3] = (uint32_t)(nodes.size() / 8);
-        return e;
-    }
-
-    // Front-to-back visiting order for one sign octant of the ray direction (bit k set = the
-    // direction is negative along axis k): at every split the child on the side the ray comes from
-    // is visited first.  link[e] = (entry to visit when e's box passes) << 16 | (entry to visit
-    // when it fails, or after e's leaf run); kLinkEnd = traversal finished.
-    void makeLinks(int octant, std::vector<uint32_t>& link) const {
-        struct Item {
-            int node, after;
-        };
-        std::vector<Item> stack{{0, (int)kLinkEnd}};
-        while (!stack.empty()) {
-            const Item it = stack.back();
-            stack.pop_back();
-            const int e = it.node;
-            if (lowChild[e] < 0) {
-                link[e] = ((uint32_t)it.after << 16) | (uint32_t)it.after;
-                continue;
-            }
-            const bool negative = splitAxis[e] >= 0 && ((octant >> splitAxis[e]) & 1);
-            const int first = negative ? highChild[e] : lowChild[e];
-            const int second = negative ? lowChild[e] : highChild[e];
-            link[e] = ((uint32_t)first << 16) | (uint32_t)it.after;
-            stack.push_back({first, second});
-            stack.push_back({second, it.after});
-        }
     }
 };
 
@@ -234,7 +190,6 @@ void Scene::buildFastStructure() {
     FlatScene& f = flat;
     f.fast_nodes.clear();
     f.fast_refs.clear();
-    f.fast_links.clear();
     f.sphere_ord.assign(spheres.size(), -1);
     f.tri_ord.assign(triangles.size(), -1);
     const size_t nRefs = f.prim_refs.size();
@@ -330,20 +285,7 @@ void Scene::buildFastStructure() {
     }
     if (prims.empty()) return;
     Builder bld{prims, f.fast_nodes, f.fast_refs};
-    if (const char* e = std::getenv("RT_FAST_LEAF")) bld.kMaxLeaf = std::max(1, std::atoi(e));
     bld.build(0, prims.size());
-    // ordered-traversal links, when entry indices fit 16 bits (otherwise the fixed order of the
-    // skip links is used)
-    const size_t nFast = f.fast_nodes.size() / 8;
-    f.fast_links.clear();
-    if (nFast < kLinkEnd) {
-        f.fast_links.resize(8 * nFast);
-        std::vector<uint32_t> one(nFast);
-        for (int oct = 0; oct < 8; oct++) {
-            bld.makeLinks(oct, one);
-            std::copy(one.begin(), one.end(), f.fast_links.begin() + (size_t)oct * nFast);
-        }
-    }
 }
 
 }  // namespace rt

@@ -65,7 +65,6 @@ struct FlatScene {
     // through `nodes` in the reference's order.
     std::vector<uint32_t> fast_nodes;   // 8 words per entry, as `nodes`
     std::vector<uint32_t> fast_refs;    // leaf references, as `prim_refs`
-    std::vector<uint32_t> fast_links;   // 8 x n entries (one table per direction-sign octant): next entry on pass << 16 | on fail; empty if n >= kLinkEnd
     std::vector<int32_t> sphere_ord;    // sphere id   -> position in prim_refs (reference visit order)
     std::vector<int32_t> tri_ord;       // triangle id -> position in prim_refs
     std::vector<int32_t> prim_guard;    // position in prim_refs -> innermost box-tested entry of `nodes` above it, or -1
@@ -77,7 +76,6 @@ constexpr uint32_t kNodeSkipMask = kNodeNoBox - 1;
 constexpr uint32_t kRefLast = 1u << 31;       // last reference of its leaf run
 constexpr uint32_t kRefTriangle = 1u << 30;
 constexpr uint32_t kRefIdMask = kRefTriangle - 1;
-constexpr uint32_t kLinkEnd = 0xFFFFu;         // ordered-traversal link: no further entry
 
 struct Camera22 {
     float origin[3], llc[3], horizontal[3], vertical[3], u[3], v[3], w[3], lens_radius;

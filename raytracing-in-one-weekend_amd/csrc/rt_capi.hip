@@ -68,7 +68,7 @@ int fail(int code, const std::string& msg) {
 
 // Largest LDS footprint the staged-scene kernel is allowed to ask for.  Two such workgroups
 // still fit the 160 KiB of a CU.
-constexpr size_t kMaxLdsScene = 78 * 1024;
+constexpr size_t kMaxLdsScene = 72 * 1024;
 
 int envInt(const char* name, int dflt) {
     const char* v = std::getenv(name);
@@ -277,7 +277,6 @@ int rt_scene_flatten(rt_scene* s, rt_flat_info* info) {
         d.n_prim_refs = info->n_prim_refs;
         d.n_fast_nodes = (int)(sc.flat.fast_nodes.size() / 8);
         d.n_fast_refs = (int)sc.flat.fast_refs.size();
-        d.ordered = sc.flat.fast_links.empty() ? 0 : 1;
         d.n_spheres = info->n_spheres;
         d.n_tris = info->n_triangles;
         d.n_mats = info->n_materials;
@@ -448,7 +447,6 @@ int rt_upload_scene(rt_context* ctx, rt_scene* s) {
     std::memcpy(fastNodes.data(), sc.flat.fast_nodes.data(), sc.flat.fast_nodes.size() * 4);
     if ((rc = devUpload(ctx, fastNodes, &d.fast_nodes))) return rc;
     if ((rc = devUpload(ctx, sc.flat.fast_refs, &d.fast_refs))) return rc;
-    if ((rc = devUpload(ctx, sc.flat.fast_links, &d.fast_links))) return rc;
     if ((rc = devUpload(ctx, sc.flat.sphere_ord, &d.sphere_ord))) return rc;
     if ((rc = devUpload(ctx, sc.flat.tri_ord, &d.tri_ord))) return rc;
     if ((rc = devUpload(ctx, sc.flat.prim_guard, &d.prim_guard))) return rc;
@@ -467,7 +465,6 @@ int rt_upload_scene(rt_context* ctx, rt_scene* s) {
     d.n_fast_nodes = (int)(sc.flat.fast_nodes.size() / 8);
     d.n_fast_refs = (int)sc.flat.fast_refs.size();
     d.force_ref = ctx->force_ref;
-    d.ordered = sc.flat.fast_links.empty() ? 0 : 1;
     d.n_spheres = (int)sc.spheres.size();
     d.n_tris = (int)sc.triangles.size();
     d.n_mats = (int)sc.materials.size();

@@ -14,7 +14,6 @@ struct DevScene {
     // search structure traversed first (same entry format, padded boxes) and its guard data
     const float4* fast_nodes;
     const uint32_t* fast_refs;
-    const uint32_t* fast_links;  // 8 x n_fast_nodes: front-to-back order per direction-sign octant, or unused (ordered == 0)
     const int* sphere_ord;    // sphere id   -> position in prim_refs (the reference's visit order)
     const int* tri_ord;       // triangle id -> position in prim_refs
     const int* prim_guard;    // position in prim_refs -> innermost box-tested entry of `nodes` above it, or -1
@@ -30,7 +29,6 @@ struct DevScene {
     const int4* tex_desc;     // {first texel, width, height, 0}
     const float* lut;         // 256-entry 8-bit -> float map
     int n_nodes, n_prim_refs, n_fast_nodes, n_fast_refs, n_spheres, n_tris, n_mats;
-    int ordered;              // 1: fast_links holds the per-octant visiting order
     int force_ref;            // 1: always walk `nodes` in the reference's order (diagnostics)
     float cam[22];            // origin, lowerLeftCorner, horizontal, vertical, u, v, w, lensRadius
     float bg[3];
@@ -53,14 +51,14 @@ struct RenderArgs {
 
 constexpr int kTile = 8;  // one wave64 = one 8x8 pixel tile
 
-// Bytes of LDS the staged scene tables need, each block 16-byte aligned (order = stageScene()):
-// the search structure with its order links, the primitives and the material tables.  The
-// reference-order arrays and the guard tables stay in HBM/L2 (one box per shaded hit).
+// Bytes of LDS the staged scene tables need, each block 16-byte aligned (order = stageScene()).
 inline size_t ldsSceneBytes(const DevScene& s) {
     auto al = [](size_t x) { return (x + 15) & ~size_t(15); };
-    return al((size_t)s.n_fast_nodes * 32) + al((size_t)s.n_fast_refs * 4) +
-           al(s.ordered ? (size_t)s.n_fast_nodes * 32 : 0) + al((size_t)s.n_spheres * 16) + al((size_t)s.n_tris * 48) +
-           al((size_t)s.n_spheres * 4) + al((size_t)s.n_tris * 4) + al((size_t)s.n_mats * 32);
+    return al((size_t)s.n_nodes * 32) + al((size_t)s.n_prim_refs * 4) + al((size_t)s.n_fast_nodes * 32) +
+           al((size_t)s.n_fast_refs * 4) + al((size_t)s.n_spheres * 16) + al((size_t)s.n_tris * 48) +
+           al((size_t)s.n_spheres * 4) + al((size_t)s.n_tris * 4) + al((size_t)s.n_mats * 32) +
+           al((size_t)s.n_spheres * 4) + al((size_t)s.n_tris * 4) + al((size_t)s.n_prim_refs * 4) +
+           al((size_t)s.n_nodes * 4);
 }
 
 }  // namespace rt

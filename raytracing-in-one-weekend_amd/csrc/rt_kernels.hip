@@ -83,7 +83,6 @@ struct SceneView {
     const uint32_t* refs;
     const float4* fnodes;   // search structure traversed first
     const uint32_t* frefs;
-    const uint32_t* flinks;  // per-octant visiting order of fnodes (DevScene::ordered)
     const float4* spheres;
     const float4* tris;
     const int* sphere_mat;
@@ -96,8 +95,8 @@ struct SceneView {
 };
 
 __device__ __forceinline__ SceneView globalView(const DevScene& sc) {
-    return SceneView{sc.nodes,      sc.prim_refs, sc.fast_nodes, sc.fast_refs, sc.fast_links, sc.spheres,    sc.tri_isect,
-                     sc.sphere_mat, sc.tri_mat,   sc.materials,  sc.sphere_ord, sc.tri_ord,   sc.prim_guard, sc.node_outer};
+    return SceneView{sc.nodes,      sc.prim_refs, sc.fast_nodes, sc.fast_refs,  sc.spheres,    sc.tri_isect, sc.sphere_mat,
+                     sc.tri_mat,    sc.materials, sc.sphere_ord, sc.tri_ord,    sc.prim_guard, sc.node_outer};
 }
 
 constexpr int kNumStats = 14;
@@ -254,33 +253,15 @@ __device__ __forceinline__ Hit traverseRef(const SceneView& sv, int n_nodes, con
     return h;
 }
 
-
-// Sign octant of the ray direction: selects the front-to-back visiting order of the search structure.
-__device__ __forceinline__ int octantOf(const V3& d) {
-    return (d.x < 0.0f ? 1 : 0) | (d.y < 0.0f ? 2 : 0) | (d.z < 0.0f ? 4 : 0);
-}
-
-// Walk over the search structure: tighter tree, padded boxes, order-independent update.  With
-// order links the entries are visited front to back for this ray's direction octant
-// (link = next entry on pass << 16 | next entry on fail or after a leaf run); without them, in
-// the fixed order of the skip links.
+// The same walk over the search structure: tighter tree, padded boxes, order-independent update.
 template <bool COUNT>
-__device__ __forceinline__ Hit traverseFast(const DevScene& sc, const SceneView& sv, const Ray& r, float invx, float invy,
-                                            float invz, float a, bool& bad, Stats* st) {
+__device__ __forceinline__ Hit traverseFast(const SceneView& sv, int n_nodes, const Ray& r, float invx, float invy, float invz,
+                                            float a, bool& bad, Stats* st) {
     Hit h{__builtin_inff(), kNoHit, 0.0f, 0.0f};
-    const int n_nodes = sc.n_fast_nodes;
-    const uint32_t* links = sv.flinks + octantOf(r.d) * n_nodes;
     int idx = 0;
     while (idx < n_nodes) {
         const float4 n0 = sv.fnodes[2 * idx], n1 = sv.fnodes[2 * idx + 1];
         const int first = (int)fbits(n1.w);
-        uint32_t nextPass = (uint32_t)idx + 1u, nextFail = fbits(n0.w) & kSkipMask;
-        if (sc.ordered) {
-            const uint32_t lk = links[idx];
-            nextPass = lk >> 16;
-            nextFail = lk & 0xFFFFu;
-            if (first >= 0) nextPass = nextFail;
-        }
         if (COUNT) st->v[C_NODE]++;
         if (slabPass(n0, n1, r, invx, invy, invz, h.t)) {
             if (first >= 0) {
@@ -291,9 +272,9 @@ __device__ __forceinline__ Hit traverseFast(const DevScene& sc, const SceneView&
                     primAnyOrder<COUNT>(sv, ref, r, a, h, bad, st);
                 } while (!(ref & kRefLast));
             }
-            idx = (int)nextPass;
+            idx = idx + 1;
         } else {
-            idx = (int)nextFail;
+            idx = (int)(fbits(n0.w) & kSkipMask);
         }
     }
     return h;
@@ -327,7 +308,7 @@ __device__ __forceinline__ Hit closestHit(const DevScene& sc, const SceneView& s
     const float a = dot(r.d, r.d);
     if (!sc.force_ref && finite3(invx, invy, invz)) {
         bool bad = false;
-        Hit h = traverseFast<COUNT>(sc, sv, r, invx, invy, invz, a, bad, st);
+        Hit h = traverseFast<COUNT>(sv, sc.n_fast_nodes, r, invx, invy, invz, a, bad, st);
         if (!bad && (h.ref == kNoHit || guardsPass<COUNT>(sv, r, invx, invy, invz, h, st))) return h;
         if (COUNT) st->v[C_FALLBACK]++;
     }
@@ -545,15 +526,20 @@ __device__ __forceinline__ SceneView stageScene(const DevScene& sc) {
         for (int i = tid; i < n; i += nt) dst[i] = src[i];
         return dst;
     };
-    SceneView v = globalView(sc);  // reference-order arrays and guard tables stay in HBM/L2
+    SceneView v;
+    v.nodes = take16(sc.nodes, sc.n_nodes * 2);
+    v.refs = take4(sc.prim_refs, sc.n_prim_refs);
     v.fnodes = take16(sc.fast_nodes, sc.n_fast_nodes * 2);
     v.frefs = take4(sc.fast_refs, sc.n_fast_refs);
-    v.flinks = take4(sc.fast_links, sc.ordered ? sc.n_fast_nodes * 8 : 0);
     v.spheres = take16(sc.spheres, sc.n_spheres);
     v.tris = take16(sc.tri_isect, sc.n_tris * 3);
     v.sphere_mat = reinterpret_cast<const int*>(take4(reinterpret_cast<const uint32_t*>(sc.sphere_mat), sc.n_spheres));
     v.tri_mat = reinterpret_cast<const int*>(take4(reinterpret_cast<const uint32_t*>(sc.tri_mat), sc.n_tris));
     v.materials = take16(sc.materials, sc.n_mats * 2);
+    v.sphere_ord = reinterpret_cast<const int*>(take4(reinterpret_cast<const uint32_t*>(sc.sphere_ord), sc.n_spheres));
+    v.tri_ord = reinterpret_cast<const int*>(take4(reinterpret_cast<const uint32_t*>(sc.tri_ord), sc.n_tris));
+    v.prim_guard = reinterpret_cast<const int*>(take4(reinterpret_cast<const uint32_t*>(sc.prim_guard), sc.n_prim_refs));
+    v.node_outer = reinterpret_cast<const int*>(take4(reinterpret_cast<const uint32_t*>(sc.node_outer), sc.n_nodes));
     __syncthreads();
     return v;
 }
@@ -670,7 +656,6 @@ __global__ void __launch_bounds__(1024) renderWavefront(RenderArgs a) {
     // 0: the lane walks the search structure; 1: it walks the reference-order array (diagnostic
     // setting, zero direction component, or a re-trace after a failed guard test / NaN distance)
     int mode = 0;
-    int linkBase = 0;  // direction-sign octant of the current ray * number of search-structure entries
 
     // wave-local pool of pixel slots pulled from the launch-wide queue 64 at a time
     int poolNext = 0, poolEnd = 0;
@@ -686,7 +671,6 @@ __global__ void __launch_bounds__(1024) renderWavefront(RenderArgs a) {
         idx = 0;
         op = OP_BOX;
         mode = (sc.force_ref || !finite3(invx, invy, invz)) ? 1 : 0;
-        linkBase = octantOf(r.d) * nNodesFast;
         if (COUNT) st.v[C_RAYS]++;
     };
     auto retraceInReferenceOrder = [&]() {
@@ -744,43 +728,27 @@ __global__ void __launch_bounds__(1024) renderWavefront(RenderArgs a) {
                     schedLanes[5] += popc64(__ballot(op == OP_BOX));
                 }
                 if (op == OP_BOX) {
-                    // Search structure: entry from LDS (or L2), the next entry from the order link of
-                    // this ray's octant.  Reference-order array: next entry is idx + 1 on a pass and
-                    // the skip link on a miss.  A leaf run is tested before moving on; idx already
-                    // names the entry that follows it.
-                    float4 n0, n1;
-                    uint32_t nextPass, nextFail;
-                    int nNodes;
-                    if (mode) {
-                        n0 = sv.nodes[2 * idx];
-                        n1 = sv.nodes[2 * idx + 1];
-                        nextPass = (uint32_t)idx + 1u;
-                        nextFail = fbits(n0.w) & kSkipMask;
-                        nNodes = nNodesRef;
-                    } else {
-                        n0 = sv.fnodes[2 * idx];
-                        n1 = sv.fnodes[2 * idx + 1];
-                        nextPass = (uint32_t)idx + 1u;
-                        nextFail = fbits(n0.w) & kSkipMask;
-                        if (sc.ordered) {
-                            const uint32_t lk = sv.flinks[linkBase + idx];
-                            nextPass = (int)fbits(n1.w) >= 0 ? (lk & 0xFFFFu) : (lk >> 16);
-                            nextFail = lk & 0xFFFFu;
-                        }
-                        nNodes = nNodesFast;
-                    }
+                    const float4* nd = mode ? sv.nodes : sv.fnodes;
+                    const int nNodes = mode ? nNodesRef : nNodesFast;
+                    const float4 n0 = nd[2 * idx], n1 = nd[2 * idx + 1];
+                    const uint32_t w3 = fbits(n0.w);
                     const int first = (int)fbits(n1.w);
-                    // list entries of the reference array (box words zero) are not box-tested
-                    const bool nobox = mode && (fbits(n0.w) & kNoBox) != 0;
+                    // the box is tested even for list entries (whose box words are zero) so that
+                    // both node words are fetched together; the flag then overrides the outcome
+                    const bool nobox = (w3 & kNoBox) != 0;
                     if (COUNT && !nobox) st.v[C_NODE]++;
                     const bool pass = slabPass(n0, n1, r, invx, invy, invz, h.t) || nobox;
-                    idx = (int)(pass ? nextPass : nextFail);
-                    if (pass && first >= 0) {
-                        p = first;
-                        op = OP_PRIM;
-                    } else if (idx >= nNodes) {
-                        op = OP_SHADE;
+                    if (pass) {
+                        if (first >= 0) {
+                            p = first;
+                            op = OP_PRIM;
+                        } else {
+                            idx += 1;
+                        }
+                    } else {
+                        idx = (int)(w3 & kSkipMask);
                     }
+                    if (op == OP_BOX && idx >= nNodes) op = OP_SHADE;
                 }
             } while (popc64(__ballot(op == OP_BOX)) >= keep && keep > 0);
         } else if (chosen == OP_PRIM) {
@@ -795,6 +763,7 @@ __global__ void __launch_bounds__(1024) renderWavefront(RenderArgs a) {
                 if (bad) {
                     retraceInReferenceOrder();
                 } else if (ref & kRefLast) {
+                    idx += 1;
                     op = idx < (mode ? nNodesRef : nNodesFast) ? OP_BOX : OP_SHADE;
                 } else {
                     p += 1;
