@@ -15,7 +15,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librtiow_hip.so")
+LIB_PATH = os.environ.get("RTIOW_LIB", os.path.join(_HERE, "librtiow_hip.so"))  # RTIOW_LIB: experimental builds
 if not os.path.exists(LIB_PATH):
     raise ImportError(
         f"{LIB_PATH} is missing: build it with `make -C {_HERE}/csrc` "

@@ -63,8 +63,9 @@ struct Builder {
 
     int newEntry(const float* mn, const float* mx) {
         int idx = (int)(nodes.size() / 8);
-        uint32_t w[8] = {u32(mn[0]), u32(mn[1]), u32(mn[2]), (uint32_t)(idx + 1),
-                         u32(mx[0]), u32(mx[1]), u32(mx[2]), 0xFFFFFFFFu};
+        // search-structure entry: {min.x, max.x, min.y, max.y, min.z, max.z, skip, first_ref}
+        uint32_t w[8] = {u32(mn[0]), u32(mx[0]), u32(mn[1]), u32(mx[1]),
+                         u32(mn[2]), u32(mx[2]), (uint32_t)(idx + 1), 0xFFFFFFFFu};
         nodes.insert(nodes.end(), w, w + 8);
         return idx;
     }
@@ -180,7 +181,7 @@ struct Builder {
             build(start, mid);
             build(mid, end);
         }
-        nodes[(size_t)e * 8 + 3] = (uint32_t)(nodes.size() / 8);
+        nodes[(size_t)e * 8 + 6] = (uint32_t)(nodes.size() / 8);
     }
 };
 

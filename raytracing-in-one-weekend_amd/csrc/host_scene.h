@@ -63,7 +63,7 @@ struct FlatScene {
     // primitives with padded boxes, in the same threaded entry format.  Its answer is accepted
     // only if the guard boxes of the hit primitive pass; otherwise the ray is traced again
     // through `nodes` in the reference's order.
-    std::vector<uint32_t> fast_nodes;   // 8 words per entry, as `nodes`
+    std::vector<uint32_t> fast_nodes;   // 8 words per entry: {min.x, max.x, min.y, max.y, min.z, max.z, skip, first_ref}
     std::vector<uint32_t> fast_refs;    // leaf references, as `prim_refs`
     std::vector<int32_t> sphere_ord;    // sphere id   -> position in prim_refs (reference visit order)
     std::vector<int32_t> tri_ord;       // triangle id -> position in prim_refs

@@ -50,6 +50,7 @@ struct rt_context {
     unsigned long long* counters = nullptr;
     std::atomic<int> cancel{0};
     int force_ref = 0;
+    bool huge_coords = false;
     unsigned long long sched_stats[14] = {0};  // from the last rt_count(): {executions, lanes} per operation
 };
 
@@ -375,7 +376,7 @@ int rt_set_stream(rt_context* ctx, void* hip_stream) {
 int rt_set_reference_traversal(rt_context* ctx, int on) {
     if (!ctx) return fail(RT_ERR_INVALID, "null context");
     ctx->force_ref = on ? 1 : 0;
-    ctx->dsc.force_ref = ctx->force_ref;
+    ctx->dsc.force_ref = (ctx->force_ref || ctx->huge_coords) ? 1 : 0;
     return RT_OK;
 }
 
@@ -392,6 +393,13 @@ int rt_upload_scene(rt_context* ctx, rt_scene* s) {
 
     const int nNodes = (int)(sc.flat.nodes.size() / 8);
     if ((uint32_t)nNodes >= rt::kNodeSkipMask) return fail(RT_ERR_LIMIT, "too many BVH entries");
+    // the search structure's fused box test multiplies plane coordinates by reciprocal directions
+    // of up to 1e30: beyond 1e7 that could overflow, so such scenes walk the reference-order array
+    bool hugeCoords = false;
+    for (const auto& sp : sc.spheres)
+        for (int k = 0; k < 3; k++) hugeCoords = hugeCoords || !(std::fabs(sp.c[k]) + std::fabs(sp.r) < 1e7f);
+    for (const auto& t : sc.triangles)
+        for (int k = 0; k < 9; k++) hugeCoords = hugeCoords || !(std::fabs(t.pos[k]) < 1e7f);
     std::vector<float4> spheres(sc.spheres.size());
     std::vector<int> sphereMat(sc.spheres.size());
     for (size_t i = 0; i < sc.spheres.size(); i++) {
@@ -464,7 +472,8 @@ int rt_upload_scene(rt_context* ctx, rt_scene* s) {
     d.n_prim_refs = (int)sc.flat.prim_refs.size();
     d.n_fast_nodes = (int)(sc.flat.fast_nodes.size() / 8);
     d.n_fast_refs = (int)sc.flat.fast_refs.size();
-    d.force_ref = ctx->force_ref;
+    d.force_ref = (ctx->force_ref || hugeCoords) ? 1 : 0;
+    ctx->huge_coords = hugeCoords;
     d.n_spheres = (int)sc.spheres.size();
     d.n_tris = (int)sc.triangles.size();
     d.n_mats = (int)sc.materials.size();

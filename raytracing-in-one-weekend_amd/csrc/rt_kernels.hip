@@ -133,6 +133,25 @@ __device__ __forceinline__ bool slabPass(const float4& n0, const float4& n1, con
     return !(tmax <= tmin);
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Box test of the search structure.  It only has to be conservative (never cull a box that
+// holds an accepted hit): which primitive wins is decided by the exact primitive tests and the
+// guard test afterwards, and the boxes are padded far beyond the rounding error of this
+// arithmetic.  So it is written for speed: t = plane * (1/d) - o * (1/d) as one fused multiply-add
+// per plane (two planes per packed instruction; the entry stores {min, max} pairs per axis), and
+// min/max instead of compare-and-swap.  Rays with a zero or denormal direction component never
+// get here (they walk the reference-order array).
+__device__ __forceinline__ bool slabPassFast(const float4& a, const float4& b, float invx, float invy, float invz,
+                                             float nox, float noy, float noz, float closest) {
+    const f32x2 tx = __builtin_elementwise_fma(f32x2{a.x, a.y}, f32x2{invx, invx}, f32x2{nox, nox});
+    const f32x2 ty = __builtin_elementwise_fma(f32x2{a.z, a.w}, f32x2{invy, invy}, f32x2{noy, noy});
+    const f32x2 tz = __builtin_elementwise_fma(f32x2{b.x, b.y}, f32x2{invz, invz}, f32x2{noz, noz});
+    const float tn = fmaxf(fmaxf(fminf(tx.x, tx.y), fminf(ty.x, ty.y)), fmaxf(fminf(tz.x, tz.y), kTMin));
+    const float tf = fminf(fminf(fmaxf(tx.x, tx.y), fmaxf(ty.x, ty.y)), fminf(fmaxf(tz.x, tz.y), closest));
+    return tn <= tf;
+}
+
 // Sphere::Hit / Triangle::Hit (R/src/Core/Hittable.h:228-255, 58-141) for one leaf reference:
 // true with the hit distance (and a triangle's barycentrics) if the primitive is hit within
 // [0.001, tMax].  `tMax < t` rejects, equality accepts, as in the reference.
@@ -253,17 +272,19 @@ __device__ __forceinline__ Hit traverseRef(const SceneView& sv, int n_nodes, con
     return h;
 }
 
-// The same walk over the search structure: tighter tree, padded boxes, order-independent update.
+// The same walk over the search structure: tighter tree, padded boxes, conservative box test,
+// order-independent update.
 template <bool COUNT>
 __device__ __forceinline__ Hit traverseFast(const SceneView& sv, int n_nodes, const Ray& r, float invx, float invy, float invz,
                                             float a, bool& bad, Stats* st) {
     Hit h{__builtin_inff(), kNoHit, 0.0f, 0.0f};
+    const float nox = -(r.o.x * invx), noy = -(r.o.y * invy), noz = -(r.o.z * invz);
     int idx = 0;
     while (idx < n_nodes) {
         const float4 n0 = sv.fnodes[2 * idx], n1 = sv.fnodes[2 * idx + 1];
         const int first = (int)fbits(n1.w);
         if (COUNT) st->v[C_NODE]++;
-        if (slabPass(n0, n1, r, invx, invy, invz, h.t)) {
+        if (slabPassFast(n0, n1, invx, invy, invz, nox, noy, noz, h.t)) {
             if (first >= 0) {
                 int p = first;
                 uint32_t ref;
@@ -274,7 +295,7 @@ __device__ __forceinline__ Hit traverseFast(const SceneView& sv, int n_nodes, co
             }
             idx = idx + 1;
         } else {
-            idx = (int)(fbits(n0.w) & kSkipMask);
+            idx = (int)fbits(n1.z);
         }
     }
     return h;
@@ -295,9 +316,13 @@ __device__ __forceinline__ bool guardsPass(const SceneView& sv, const Ray& r, fl
     return true;
 }
 
-__device__ __forceinline__ bool finite3(float x, float y, float z) {
-    const float inf = __builtin_inff();
-    return fabsf(x) < inf && fabsf(y) < inf && fabsf(z) < inf;
+// True if the reciprocal direction is usable by the search structure's fused box test: every
+// component finite and small enough that plane * (1/d) cannot overflow (scene coordinates are
+// limited to 1e7 on upload).  False (also for NaN) sends the ray to the reference-order walk.
+__device__ __forceinline__ bool fastTestUsable(float invx, float invy, float invz, float nox, float noy, float noz) {
+    const float lim = 1e30f, inf = __builtin_inff();
+    return fabsf(invx) < lim && fabsf(invy) < lim && fabsf(invz) < lim && fabsf(nox) < inf && fabsf(noy) < inf &&
+           fabsf(noz) < inf;
 }
 
 // mWorld.Hit(r, 0.001f, infinity, rec) (R/src/Core/Raytracer.cpp:10): search structure first,
@@ -306,7 +331,7 @@ template <bool COUNT>
 __device__ __forceinline__ Hit closestHit(const DevScene& sc, const SceneView& sv, const Ray& r, Stats* st) {
     const float invx = 1.0f / r.d.x, invy = 1.0f / r.d.y, invz = 1.0f / r.d.z;
     const float a = dot(r.d, r.d);
-    if (!sc.force_ref && finite3(invx, invy, invz)) {
+    if (!sc.force_ref && fastTestUsable(invx, invy, invz, -(r.o.x * invx), -(r.o.y * invy), -(r.o.z * invz))) {
         bool bad = false;
         Hit h = traverseFast<COUNT>(sv, sc.n_fast_nodes, r, invx, invy, invz, a, bad, st);
         if (!bad && (h.ref == kNoHit || guardsPass<COUNT>(sv, r, invx, invy, invz, h, st))) return h;
@@ -652,6 +677,7 @@ __global__ void __launch_bounds__(1024) renderWavefront(RenderArgs a) {
     Rng rng{0u, 0u};
     Ray r{{0.f, 0.f, 0.f}, {0.f, 0.f, 1.f}};
     float invx = 0.f, invy = 0.f, invz = 0.f, aa = 1.f;
+    float nox = 0.f, noy = 0.f, noz = 0.f;  // -origin / direction, for the search structure's box test
     Hit h{0.f, kNoHit, 0.f, 0.f};
     // 0: the lane walks the search structure; 1: it walks the reference-order array (diagnostic
     // setting, zero direction component, or a re-trace after a failed guard test / NaN distance)
@@ -670,7 +696,10 @@ __global__ void __launch_bounds__(1024) renderWavefront(RenderArgs a) {
         h.ref = kNoHit;
         idx = 0;
         op = OP_BOX;
-        mode = (sc.force_ref || !finite3(invx, invy, invz)) ? 1 : 0;
+        nox = -(r.o.x * invx);
+        noy = -(r.o.y * invy);
+        noz = -(r.o.z * invz);
+        mode = (sc.force_ref || !fastTestUsable(invx, invy, invz, nox, noy, noz)) ? 1 : 0;
         if (COUNT) st.v[C_RAYS]++;
     };
     auto retraceInReferenceOrder = [&]() {
@@ -728,16 +757,25 @@ __global__ void __launch_bounds__(1024) renderWavefront(RenderArgs a) {
                     schedLanes[5] += popc64(__ballot(op == OP_BOX));
                 }
                 if (op == OP_BOX) {
-                    const float4* nd = mode ? sv.nodes : sv.fnodes;
-                    const int nNodes = mode ? nNodesRef : nNodesFast;
-                    const float4 n0 = nd[2 * idx], n1 = nd[2 * idx + 1];
-                    const uint32_t w3 = fbits(n0.w);
-                    const int first = (int)fbits(n1.w);
-                    // the box is tested even for list entries (whose box words are zero) so that
-                    // both node words are fetched together; the flag then overrides the outcome
-                    const bool nobox = (w3 & kNoBox) != 0;
-                    if (COUNT && !nobox) st.v[C_NODE]++;
-                    const bool pass = slabPass(n0, n1, r, invx, invy, invz, h.t) || nobox;
+                    bool pass;
+                    int first, skip, nNodes;
+                    if (mode == 0) {  // search structure: conservative fused test
+                        const float4 n0 = sv.fnodes[2 * idx], n1 = sv.fnodes[2 * idx + 1];
+                        first = (int)fbits(n1.w);
+                        skip = (int)fbits(n1.z);
+                        nNodes = nNodesFast;
+                        if (COUNT) st.v[C_NODE]++;
+                        pass = slabPassFast(n0, n1, invx, invy, invz, nox, noy, noz, h.t);
+                    } else {  // reference-order array: the reference's own test; list entries have none
+                        const float4 n0 = sv.nodes[2 * idx], n1 = sv.nodes[2 * idx + 1];
+                        const uint32_t w3 = fbits(n0.w);
+                        first = (int)fbits(n1.w);
+                        skip = (int)(w3 & kSkipMask);
+                        nNodes = nNodesRef;
+                        const bool nobox = (w3 & kNoBox) != 0;
+                        if (COUNT && !nobox) st.v[C_NODE]++;
+                        pass = slabPass(n0, n1, r, invx, invy, invz, h.t) || nobox;
+                    }
                     if (pass) {
                         if (first >= 0) {
                             p = first;
@@ -746,7 +784,7 @@ __global__ void __launch_bounds__(1024) renderWavefront(RenderArgs a) {
                             idx += 1;
                         }
                     } else {
-                        idx = (int)(w3 & kSkipMask);
+                        idx = skip;
                     }
                     if (op == OP_BOX && idx >= nNodes) op = OP_SHADE;
                 }
