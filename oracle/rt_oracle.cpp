@@ -519,8 +519,20 @@ inline bool boxCompare(const HPtr& a, const HPtr& b, int axis) {  // Bvh.cpp:3-1
 struct BVHNode : Hittable {  // Bvh.h:13-100
     HPtr left, right;
     AABB box;
+    // Bvh.h:20 copies the whole source vector in every node and sorts its own [start, end) of the
+    // copy.  The children receive the parent's sorted copy and touch only their own disjoint
+    // sub-ranges, so one working copy sorted in place gives every node exactly the elements and
+    // order it would see in its private copy; the per-node copy (quadratic in the object count)
+    // is therefore made once, at the root.
     BVHNode(const std::vector<HPtr>& src, size_t start, size_t end, int maxDepth, Rng& rng) {
-        auto objects = src;  // :20 (whole-vector copy, as the reference does)
+        auto objects = src;
+        build(objects, start, end, maxDepth, rng);
+    }
+    struct InPlace {};
+    BVHNode(InPlace, std::vector<HPtr>& objects, size_t start, size_t end, int maxDepth, Rng& rng) {
+        build(objects, start, end, maxDepth, rng);
+    }
+    void build(std::vector<HPtr>& objects, size_t start, size_t end, int maxDepth, Rng& rng) {
         int axis = rng.randomInt(0, 2);
         auto comparator = [axis](const HPtr& a, const HPtr& b) { return boxCompare(a, b, axis); };
         size_t span = end - start;
@@ -544,8 +556,8 @@ struct BVHNode : Hittable {  // Bvh.h:13-100
                 left = l;
                 right = r;
             } else {
-                left = std::make_shared<BVHNode>(objects, start, mid, maxDepth - 1, rng);
-                right = std::make_shared<BVHNode>(objects, mid, end, maxDepth - 1, rng);
+                left = std::make_shared<BVHNode>(InPlace{}, objects, start, mid, maxDepth - 1, rng);
+                right = std::make_shared<BVHNode>(InPlace{}, objects, mid, end, maxDepth - 1, rng);
             }
         }
         AABB bl, br;

@@ -1,0 +1,139 @@
+"""Timing of the other BASELINE.json configurations (parity-test cases, not the bench line):
+
+  C1  cover scene 1200x675, 10 spp                      (the reference's CPU-runnable case)
+  C3  Cornell box + brass vase (glTF fixture, 2,760 triangles), three synthetic 4096^2 maps, 1080p 256 spp
+  C5s instanced vases on a jittered grid, N triangles (default 1e6), 1080p, unlimited-depth reference BVH
+
+Each case: upload, one timed launch (HIP events), path counters, and a bit-exact spot check of a few
+image rows against the CPU oracle.  Prints one JSON line per case.
+
+Usage: python profiles/bench_configs.py [c1] [c3] [c5s[:triangles]]
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from __graft_entry__ import load_oracle, load_package  # noqa: E402
+
+rt = load_package()
+orc = load_oracle()
+from rtiow_amd import scenes  # noqa: E402
+
+G = os.path.join(ROOT, "tests", "golden", "brass_vase", "brass_vase_04_4k.gltf")
+
+
+def run(name, build, w, h, spp, check_rows, oracle_spp=None):
+    t0 = time.perf_counter()
+    a = rt.Scene()
+    build(a)
+    info = a.flatten()
+    t_host = time.perf_counter() - t0
+    ctx = rt.Context(0)
+    ctx.upload_scene(a)
+    ctx.set_target(w, h)
+    ctx.render(0, min(spp, 2), 50)   # warm-up launch
+    ctx.sync()
+    ctx.clear()
+    ctx.render(0, spp, 50)
+    ctx.sync()
+    ms = ctx.last_render_ms()
+    img = ctx.read_accum()
+    print(f"[{name}] host build {t_host:.1f} s, kernel {ms:.2f} ms", file=sys.stderr, flush=True)
+    cnt = ctx.count(0, min(spp, 4), 50)
+    out = {"case": name, "size": [w, h], "spp": spp, "kernel_ms": round(ms, 3),
+           "msamples_per_s": round(w * h * spp / ms / 1e3, 1), "host_build_s": round(t_host, 2),
+           "n_nodes": info.n_nodes, "n_triangles": info.n_triangles, "n_spheres": info.n_spheres,
+           "scene_in_lds": bool(info.fits_lds),
+           "rays_per_sample": round(cnt["rays"] / cnt["samples"], 3),
+           "node_tests_per_ray": round(cnt["node_tests"] / cnt["rays"], 2),
+           "prim_tests_per_ray": round((cnt["sphere_tests"] + cnt["tri_tests"]) / cnt["rays"], 2),
+           "fallbacks_per_ray": cnt["fallbacks"] / cnt["rays"]}
+    if check_rows:
+        b = orc.OracleScene()
+        t0 = time.perf_counter()
+        build(b)
+        print(f"[{name}] oracle build {time.perf_counter() - t0:.1f} s", file=sys.stderr, flush=True)
+        ospp = oracle_spp or spp
+        if ospp != spp:
+            ctx.clear()
+            ctx.render(0, ospp, 50)
+            ctx.sync()
+            img = ctx.read_accum()
+        ok = True
+        for r0 in check_rows:
+            want, _, _ = b.render(w, h, 0, ospp, 50, rng_mode=1, order=1, threads=16, row0=r0, row1=r0 + 2)
+            ok = ok and np.array_equal(img[r0:r0 + 2, :, :3].view(np.uint32), want[r0:r0 + 2, :, :3].view(np.uint32))
+        out["oracle_rows_bit_exact"] = bool(ok)
+    ctx.close()
+    print(json.dumps(out), flush=True)
+
+
+def c1():
+    run("C1 cover 1200x675x10", lambda s: scenes.cover_scene(s, 1200, 675), 1200, 675, 10, [0, 300, 600])
+
+
+def c3():
+    mesh = scenes.load_gltf_mesh(G)
+    tex = {"diffuse": scenes.noise_texture(4096, 1), "roughness": scenes.noise_texture(4096, 2),
+           "normal": scenes.noise_texture(4096, 3)}
+    run("C3 cornell+vase 1080p x256", lambda s: scenes.cornell_mesh_scene(s, 1920, 1080, mesh, tex),
+        1920, 1080, 256, [100, 540, 900], oracle_spp=4)
+
+
+def c5s(n_tris):
+    mesh = scenes.load_gltf_mesh(G)
+    per = mesh["indices"].shape[0]
+    copies = max(1, n_tris // per)
+    side = int(np.ceil(np.sqrt(copies)))
+    tex = {"diffuse": scenes.noise_texture(1024, 1), "roughness": scenes.noise_texture(1024, 2), "normal": None}
+
+    def build(s):
+        s.cornell_box()
+        td, tr = s.add_texture(tex["diffuse"]), s.add_texture(tex["roughness"])
+        mat = s.add_pbr(td, tr, -1)
+        jit = s.rng_floats(2 * copies)          # grid jitter from the scene's own generator
+        # every copy is baked into one triangle list (the reference has no instancing)
+        pos, nrm, uv, idx = [], [], [], []
+        nv = mesh["positions"].shape[0]
+        for c in range(copies):
+            gx, gz = c % side, c // side
+            off = np.array([(gx + 0.3 * jit[2 * c]) * 0.09 - 0.045 * side, 0.0,
+                            (gz + 0.3 * jit[2 * c + 1]) * 0.09], np.float32)
+            pos.append(mesh["positions"] + off)
+            nrm.append(mesh["normals"])
+            uv.append(mesh["uvs"])
+            idx.append(mesh["indices"] + np.uint32(c * nv))
+        s.add_mesh(scenes.translate_scale((277.5, 100.0, 277.5), (500.0, 500.0, 500.0)), np.concatenate(pos),
+                   np.concatenate(idx), mat, normals=np.concatenate(nrm), uvs=np.concatenate(uv), max_depth=-1)
+        s.set_camera((278.0, 400.0, -800.0), (278.0, 150.0, 300.0), (0.0, 1.0, 0.0), 40.0, 1.0, 0.0, 10.0)
+        s.set_background((0.6, 0.7, 0.9))
+
+    run(f"C5s {copies} vases = {copies * per} triangles, 1080p x16", build, 1920, 1080, 16, [540], oracle_spp=1)
+
+
+def heartbeat():
+    import threading
+
+    def tick():
+        t0 = time.perf_counter()
+        while True:
+            time.sleep(45)
+            print(f"... {time.perf_counter() - t0:.0f} s", file=sys.stderr, flush=True)
+    threading.Thread(target=tick, daemon=True).start()
+
+
+if __name__ == "__main__":
+    heartbeat()   # long host-side BVH builds print nothing themselves
+    args = sys.argv[1:] or ["c1", "c3"]
+    for a in args:
+        if a == "c1":
+            c1()
+        elif a == "c3":
+            c3()
+        elif a.startswith("c5s"):
+            c5s(int(float(a.split(":")[1])) if ":" in a else 1_000_000)
