@@ -228,10 +228,10 @@ typedef struct rt_counters {
 } rt_counters;
 int rt_count(rt_context* ctx, int first_sample, int n_samples, int max_depth, rt_counters* out);
 
-/* Diagnostics of the wavefront scheduler, filled by the last rt_count(): for each lane operation
- * (box test, primitive test, shade, sphere-sample attempt, new path, disk-sample attempt, new
- * pixel) the number of wave-level executions and the number of lanes that took part: 7 pairs.
- * No reference counterpart. */
+/* Diagnostics of the wavefront scheduler, filled by the last rt_count(): 7 pairs {wave-level
+ * executions, lanes that took part}: the times each operation was voted in (search-structure box
+ * test, primitive test, shade, new path, new pixel), then the box-test steps inside those votes,
+ * then the votes for the reference-order box test.  No reference counterpart. */
 int rt_sched_stats(rt_context* ctx, uint64_t* out14);
 
 /* Milliseconds the last rt_render() kernel took on the device (HIP events on the context's

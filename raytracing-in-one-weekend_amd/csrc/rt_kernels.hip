@@ -33,6 +33,18 @@ __device__ __forceinline__ uint32_t hashu(uint32_t x) {
 // R/assets/shaders/raytracer.comp:44-58.  The shader hashes
 // floatBitsToUint(vec4(x, y, sampleCount, counter)) as v.x ^ hash(v.y) ^ hash(v.z) ^ hash(v.w);
 // the first three terms are constant for one pixel-sample and are folded into `key`.
+//
+// The remaining term hash(floatBits(counter)) depends on the counter alone; every kernel that
+// draws random numbers tabulates it for the first kCounterLut counter values in LDS
+// (fillCounterLut) so that a draw costs one hash instead of two.
+constexpr int kCounterLut = 256;
+__shared__ uint32_t g_counterLut[kCounterLut];
+
+__device__ __forceinline__ void fillCounterLut() {
+    for (int i = threadIdx.x; i < kCounterLut; i += blockDim.x) g_counterLut[i] = hashu(fbits((float)i));
+    __syncthreads();
+}
+
 struct Rng {
     uint32_t key, counter;
     __device__ __forceinline__ void init(uint32_t px, uint32_t py, int sample) {
@@ -41,7 +53,8 @@ struct Rng {
     }
     __device__ __forceinline__ float next() {
         counter += 1;
-        uint32_t m = hashu(key ^ hashu(fbits((float)counter)));
+        const uint32_t inner = counter < (uint32_t)kCounterLut ? g_counterLut[counter] : hashu(fbits((float)counter));
+        uint32_t m = hashu(key ^ inner);
         m &= 0x007FFFFFu;
         m |= 0x3F800000u;
         return __uint_as_float(m) - 1.0f;
@@ -414,9 +427,13 @@ __device__ __forceinline__ bool scatter(const DevScene& sc, const SceneView& sv,
     const int kind = (int)fbits(m1.x);
     emit = {0.0f, 0.0f, 0.0f};
     out.o = s.p;
+    // Lambertian, Metal and PBR each draw exactly one point in the unit sphere and nothing before
+    // it, so the rejection loop runs once for all the lanes of a wave, whatever their material.
+    V3 ball{0.0f, 0.0f, 0.0f};
+    if (kind == 0 || kind == 1 || kind == 4) ball = randomInUnitSphere(rng);
     if (kind == 0) {  // Lambertian, Material.h:22-36
         if (COUNT) st->v[C_LAMB]++;
-        V3 dir = s.n + normalize(randomInUnitSphere(rng));
+        V3 dir = s.n + normalize(ball);
         // vecNearZero, R/src/Core/RTWeekend.cpp:39-43 (threshold 1e-8 as a double)
         if (((double)fabsf(dir.x) < 1e-8) && ((double)fabsf(dir.y) < 1e-8) && ((double)fabsf(dir.z) < 1e-8)) dir = s.n;
         out.d = dir;
@@ -426,7 +443,7 @@ __device__ __forceinline__ bool scatter(const DevScene& sc, const SceneView& sv,
     if (kind == 1) {  // Metal, Material.h:47-53
         if (COUNT) st->v[C_METAL]++;
         V3 reflected = reflect(normalize(in.d), s.n);
-        out.d = reflected + m0.w * randomInUnitSphere(rng);
+        out.d = reflected + m0.w * ball;
         atten = {m0.x, m0.y, m0.z};
         return dot(out.d, s.n) > 0;
     }
@@ -472,10 +489,10 @@ __device__ __forceinline__ bool scatter(const DevScene& sc, const SceneView& sv,
     if (texR >= 0) {
         V3 reflected = reflect(normalize(in.d), s.n);
         V3 rough = textureAt(sc, texR, s.u, s.v);
-        out.d = reflected + rough * randomInUnitSphere(rng);
+        out.d = reflected + rough * ball;
         return dot(out.d, s.n) > 0;
     }
-    V3 dir = s.n + normalize(randomInUnitSphere(rng));
+    V3 dir = s.n + normalize(ball);
     if (((double)fabsf(dir.x) < 1e-8) && ((double)fabsf(dir.y) < 1e-8) && ((double)fabsf(dir.z) < 1e-8)) dir = s.n;
     out.d = dir;
     return true;
@@ -575,6 +592,7 @@ __device__ __forceinline__ SceneView stageScene(const DevScene& sc) {
 template <bool LDS, bool COUNT>
 __global__ void __launch_bounds__(256) renderKernel(RenderArgs a) {
     const DevScene& sc = a.sc;
+    fillCounterLut();
     SceneView sv;
     if (LDS) {
         sv = stageScene(sc);
@@ -648,13 +666,15 @@ __global__ void __launch_bounds__(256) renderKernel(RenderArgs a) {
 // pixel from the launch-wide queue, so no lane idles until the queue is dry.  Which lane
 // runs when never changes what a lane computes: a pixel's samples are still summed by one
 // lane in sample order, and the random stream is keyed by (x, y, sample, counter).
-enum : int { OP_BOX = 0, OP_PRIM = 1, OP_SHADE = 2, OP_NEWPATH = 3, OP_NEWPIXEL = 4, OP_DONE = 5 };
+// OP_BOX walks the search structure, OP_REFBOX the reference-order array (lanes with mode == 1).
+enum : int { OP_BOX = 0, OP_PRIM = 1, OP_SHADE = 2, OP_NEWPATH = 3, OP_NEWPIXEL = 4, OP_REFBOX = 5, OP_DONE = 6 };
 
 __device__ __forceinline__ int popc64(unsigned long long m) { return __builtin_popcountll(m); }
 
 template <bool LDS, bool COUNT>
 __global__ void __launch_bounds__(1024) renderWavefront(RenderArgs a) {
     const DevScene& sc = a.sc;
+    fillCounterLut();
     SceneView sv;
     if (LDS) {
         sv = stageScene(sc);
@@ -685,7 +705,7 @@ __global__ void __launch_bounds__(1024) renderWavefront(RenderArgs a) {
 
     // wave-local pool of pixel slots pulled from the launch-wide queue 64 at a time
     int poolNext = 0, poolEnd = 0;
-    unsigned long long schedExec[6] = {0, 0, 0, 0, 0, 0}, schedLanes[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long schedExec[7] = {0, 0, 0, 0, 0, 0, 0}, schedLanes[7] = {0, 0, 0, 0, 0, 0, 0};
 
     auto startRay = [&]() {
         invx = 1.0f / r.d.x;
@@ -695,18 +715,18 @@ __global__ void __launch_bounds__(1024) renderWavefront(RenderArgs a) {
         h.t = __builtin_inff();
         h.ref = kNoHit;
         idx = 0;
-        op = OP_BOX;
         nox = -(r.o.x * invx);
         noy = -(r.o.y * invy);
         noz = -(r.o.z * invz);
         mode = (sc.force_ref || !fastTestUsable(invx, invy, invz, nox, noy, noz)) ? 1 : 0;
+        op = mode ? OP_REFBOX : OP_BOX;
         if (COUNT) st.v[C_RAYS]++;
     };
     auto retraceInReferenceOrder = [&]() {
         h.t = __builtin_inff();
         h.ref = kNoHit;
         idx = 0;
-        op = OP_BOX;
+        op = OP_REFBOX;
         mode = 1;
         if (COUNT) st.v[C_FALLBACK]++;
     };
@@ -723,21 +743,23 @@ __global__ void __launch_bounds__(1024) renderWavefront(RenderArgs a) {
         const unsigned long long mShade = __ballot(op == OP_SHADE);
         const unsigned long long mPath = __ballot(op == OP_NEWPATH);
         const unsigned long long mPixel = __ballot(op == OP_NEWPIXEL);
+        const unsigned long long mRef = __ballot(op == OP_REFBOX);
         const int cBox = popc64(mBox), cPrim = popc64(mPrim), cShade = popc64(mShade), cPath = popc64(mPath),
-                  cPixel = popc64(mPixel);
-        if ((cBox | cPrim | cShade | cPath | cPixel) == 0) break;
+                  cPixel = popc64(mPixel), cRef = popc64(mRef);
+        if ((cBox | cPrim | cShade | cPath | cPixel | cRef) == 0) break;
 
         // Pick the operation to run: the cheap bookkeeping ones first, then whichever of the
         // traversal / shading operations has the most lanes waiting (shading is the costly one,
         // so it also goes as soon as `shadeMin` lanes have piled up).
         int chosen;
-        if (cPixel > 0 && (cPixel >= 16 || (cBox | cPrim | cShade | cPath) == 0)) {
+        if (cPixel > 0 && (cPixel >= 16 || (cBox | cPrim | cShade | cPath | cRef) == 0)) {
             chosen = OP_NEWPIXEL;
         } else if (cShade >= shadeMin || cPath >= shadeMin) {
             chosen = cShade >= cPath ? OP_SHADE : OP_NEWPATH;
         } else {
             chosen = OP_BOX;
             int best = cBox;
+            if (cRef > best) { best = cRef; chosen = OP_REFBOX; }
             if (cPrim > best) { best = cPrim; chosen = OP_PRIM; }
             if (cShade > best) { best = cShade; chosen = OP_SHADE; }
             if (cPath > best) { best = cPath; chosen = OP_NEWPATH; }
@@ -745,50 +767,58 @@ __global__ void __launch_bounds__(1024) renderWavefront(RenderArgs a) {
         }
 
         if (COUNT) {  // scheduling statistics: executions and waiting lanes per operation
-            const int cnt[5] = {cBox, cPrim, cShade, cPath, cPixel};
-            schedExec[chosen] += 1;
-            schedLanes[chosen] += cnt[chosen];
+            const int cnt[6] = {cBox, cPrim, cShade, cPath, cPixel, cRef};
+            const int slot = chosen == OP_REFBOX ? 6 : chosen;
+            schedExec[slot] += 1;
+            schedLanes[slot] += cnt[chosen];
         }
         if (chosen == OP_BOX) {
-            int keep = boxKeep < cBox ? boxKeep : cBox;  // never spin below what is available
+            // Search structure: conservative fused box test.  An entry that passes and carries a
+            // leaf run sends the lane to PRIM; `idx` already names the entry to go on with.
+            const int keep = boxKeep < cBox ? boxKeep : cBox;  // never spin below what is available
             do {
                 if (COUNT) {
                     schedExec[5] += 1;
                     schedLanes[5] += popc64(__ballot(op == OP_BOX));
                 }
                 if (op == OP_BOX) {
-                    bool pass;
-                    int first, skip, nNodes;
-                    if (mode == 0) {  // search structure: conservative fused test
-                        const float4 n0 = sv.fnodes[2 * idx], n1 = sv.fnodes[2 * idx + 1];
-                        first = (int)fbits(n1.w);
-                        skip = (int)fbits(n1.z);
-                        nNodes = nNodesFast;
-                        if (COUNT) st.v[C_NODE]++;
-                        pass = slabPassFast(n0, n1, invx, invy, invz, nox, noy, noz, h.t);
-                    } else {  // reference-order array: the reference's own test; list entries have none
-                        const float4 n0 = sv.nodes[2 * idx], n1 = sv.nodes[2 * idx + 1];
-                        const uint32_t w3 = fbits(n0.w);
-                        first = (int)fbits(n1.w);
-                        skip = (int)(w3 & kSkipMask);
-                        nNodes = nNodesRef;
-                        const bool nobox = (w3 & kNoBox) != 0;
-                        if (COUNT && !nobox) st.v[C_NODE]++;
-                        pass = slabPass(n0, n1, r, invx, invy, invz, h.t) || nobox;
+                    const float4 n0 = sv.fnodes[2 * idx], n1 = sv.fnodes[2 * idx + 1];
+                    const int first = (int)fbits(n1.w);
+                    if (COUNT) st.v[C_NODE]++;
+                    const bool pass = slabPassFast(n0, n1, invx, invy, invz, nox, noy, noz, h.t);
+                    idx = pass ? idx + 1 : (int)fbits(n1.z);
+                    if (pass && first >= 0) {
+                        p = first;
+                        op = OP_PRIM;
+                    } else if (idx >= nNodesFast) {
+                        op = OP_SHADE;
                     }
-                    if (pass) {
-                        if (first >= 0) {
-                            p = first;
-                            op = OP_PRIM;
-                        } else {
-                            idx += 1;
-                        }
-                    } else {
-                        idx = skip;
-                    }
-                    if (op == OP_BOX && idx >= nNodes) op = OP_SHADE;
                 }
             } while (popc64(__ballot(op == OP_BOX)) >= keep && keep > 0);
+        } else if (chosen == OP_REFBOX) {
+            // Reference-order array: the reference's own test; list entries have no box.
+            const int keep = boxKeep < cRef ? boxKeep : cRef;
+            do {
+                if (COUNT) {
+                    schedExec[5] += 1;
+                    schedLanes[5] += popc64(__ballot(op == OP_REFBOX));
+                }
+                if (op == OP_REFBOX) {
+                    const float4 n0 = sv.nodes[2 * idx], n1 = sv.nodes[2 * idx + 1];
+                    const uint32_t w3 = fbits(n0.w);
+                    const int first = (int)fbits(n1.w);
+                    const bool nobox = (w3 & kNoBox) != 0;
+                    if (COUNT && !nobox) st.v[C_NODE]++;
+                    const bool pass = slabPass(n0, n1, r, invx, invy, invz, h.t) || nobox;
+                    idx = pass ? idx + 1 : (int)(w3 & kSkipMask);
+                    if (pass && first >= 0) {
+                        p = first;
+                        op = OP_PRIM;
+                    } else if (idx >= nNodesRef) {
+                        op = OP_SHADE;
+                    }
+                }
+            } while (popc64(__ballot(op == OP_REFBOX)) >= keep && keep > 0);
         } else if (chosen == OP_PRIM) {
             if (op == OP_PRIM) {
                 const uint32_t ref = (mode ? sv.refs : sv.frefs)[p];
@@ -801,8 +831,7 @@ __global__ void __launch_bounds__(1024) renderWavefront(RenderArgs a) {
                 if (bad) {
                     retraceInReferenceOrder();
                 } else if (ref & kRefLast) {
-                    idx += 1;
-                    op = idx < (mode ? nNodesRef : nNodesFast) ? OP_BOX : OP_SHADE;
+                    op = idx >= (mode ? nNodesRef : nNodesFast) ? OP_SHADE : (mode ? OP_REFBOX : OP_BOX);
                 } else {
                     p += 1;
                 }
@@ -899,7 +928,7 @@ __global__ void __launch_bounds__(1024) renderWavefront(RenderArgs a) {
         }
     }
     if (COUNT && lane == 0) {
-        for (int i = 0; i < 6; i++) {
+        for (int i = 0; i < 7; i++) {
             atomicAdd(&a.counters[13 + 2 * i], schedExec[i]);
             atomicAdd(&a.counters[14 + 2 * i], schedLanes[i]);
         }
@@ -949,6 +978,7 @@ __global__ void __launch_bounds__(256) traceKernel(DevScene sc, int n, const flo
 __global__ void scatterKernel(DevScene sc, int n, const int* mat, const float* rayIn, const float* p, const float* nrm,
                               const int* front, const float* uv, const unsigned int* key4, float* atten, float* rayOut,
                               int* alive, unsigned int* counterOut) {
+    fillCounterLut();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Ray in;
