@@ -42,6 +42,17 @@ def flops_from_counters(c):
     return float(sum(c[k] * v for k, v in COST.items()))
 
 
+def hbm_traffic_bytes(world, spp):
+    """HBM bytes per render launch from the committed rocprofv3 PMC passes (profiles/hbm_traffic.json,
+    written by profiles/summarize_traffic.py from the FETCH_SIZE / WRITE_SIZE runs of this same
+    workload); None when the run's configuration is not the profiled one."""
+    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if world != 1 or spp != SPP or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f).get("hbm_bytes_per_launch")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -158,8 +169,8 @@ def main():
             "peak": PEAK_FP32_TFLOPS,
             "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_FP32_TFLOPS, 4),
-            "traffic": None,
-            "kernel": "renderKernel",
+            "traffic": hbm_traffic_bytes(world, args.spp),
+            "kernel": "rt::renderWavefront<true, false>",
             "kernel_ms": round(avg_kernel_ms, 4),
             "flops_per_sample": round(flops_per_sample, 1),
             "rays_per_sample": round(counters["rays"] / counters["samples"], 3),
@@ -169,14 +180,27 @@ def main():
     ctx.close()
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # The CPU oracle (scalar restatement of the reference's algorithm) on this box's host cores,
+        # on a bounded sample of the same workload; it is the checker elsewhere, here only timed.
         orc = load_oracle()
         threads = max(1, min(16, int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))))
-        cpu_spp = 4
+        cpu_spp = 16
         o = orc.OracleScene()
         scenes.cover_scene(o, W, H, wrap_bvh=True)
         t0 = time.perf_counter()
         o.render(W, H, 0, cpu_spp, MAX_DEPTH, rng_mode=1, order=1, threads=threads)
         dt = time.perf_counter() - t0
+        # One thread, with and without the BVH (the reference application renders the flat list),
+        # on a smaller frame of the same scene: the per-core figures behind the headline one.
+        sw, sh, sspp = 480, 270, 2
+        t0 = time.perf_counter()
+        o.render(sw, sh, 0, sspp, MAX_DEPTH, rng_mode=1, order=1, threads=1)
+        dt_bvh1 = time.perf_counter() - t0
+        flat = orc.OracleScene()
+        scenes.cover_scene(flat, W, H, wrap_bvh=False)
+        t0 = time.perf_counter()
+        flat.render(sw, sh, 0, 1, MAX_DEPTH, rng_mode=1, order=1, threads=1)
+        dt_flat1 = time.perf_counter() - t0
         out["cpu_baseline"] = {
             "value": round(W * H * cpu_spp / dt / 1e6, 3),
             "unit": "Msamples/s",
@@ -184,6 +208,9 @@ def main():
             "kind": "port",
             "sample": f"same scene and camera, {W}x{H} at {cpu_spp} spp ({W * H * cpu_spp / 1e6:.1f} M samples), "
                       f"scalar CPU oracle with BVH, {threads} threads, {dt:.1f} s wall",
+            "one_thread_bvh": round(sw * sh * sspp / dt_bvh1 / 1e6, 4),
+            "one_thread_flat_list": round(sw * sh / dt_flat1 / 1e6, 4),
+            "one_thread_sample": f"{sw}x{sh}, {sspp} spp (BVH) and 1 spp (flat list, as the reference application renders)",
         }
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -1,0 +1,40 @@
+"""Writes profiles/hbm_traffic.json from the FETCH_SIZE / WRITE_SIZE passes of profiles/run_profile.sh.
+
+rocprofv3 reports both counters in kilobytes.  On gfx950 FETCH_SIZE tallies the 128-byte read
+requests of wide coalesced loads (16 B per lane, the accumulation-buffer reads here) at 64 bytes,
+so it is doubled; WRITE_SIZE is exact for 16-B-per-lane stores.  bytes = (2 * fetch + write) * 1024.
+Usage: python profiles/summarize_traffic.py gpurun_out/prof_<tag>"""
+import glob
+import json
+import os
+import sqlite3
+import sys
+
+
+def per_dispatch(root, counter):
+    for db_path in sorted(glob.glob(os.path.join(root, "*", "*_results.db"))):
+        cur = sqlite3.connect(db_path).cursor()
+        try:
+            rows = list(cur.execute(
+                "select sum(value) / count(distinct dispatch_id) from counters_collection "
+                "where counter_name = ? and kernel_name like '%renderWavefront<true, false>%'", (counter,)))
+        except sqlite3.Error:
+            continue
+        if rows and rows[0][0] is not None:
+            return float(rows[0][0])
+    return None
+
+
+def main(root):
+    rd, wr = per_dispatch(root, "FETCH_SIZE"), per_dispatch(root, "WRITE_SIZE")
+    out = {"source": os.path.basename(os.path.normpath(root)), "fetch_kb_per_launch": rd, "write_kb_per_launch": wr,
+           "hbm_bytes_per_launch": None if rd is None or wr is None else int((2.0 * rd + wr) * 1024),
+           "workload": "bench.py default: cover scene 1920x1080, 64 spp, 1 GPU"}
+    here = os.path.dirname(os.path.abspath(__file__))
+    with open(os.path.join(here, "hbm_traffic.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print(out)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])

@@ -151,7 +151,7 @@ int launch(rt_context* ctx, rt::RenderArgs& a, bool count) {
     }
     HIP_TRY(hipMemsetAsync(ctx->queue, 0, 256, ctx->stream));
     a.queue = ctx->queue;
-    a.knob[0] = envInt("RT_BOX_KEEP", 8);
+    a.knob[0] = envInt("RT_BOX_KEEP", 4);
     a.knob[1] = envInt("RT_SHADE_MIN", 32);
     int wfThreads = envInt("RT_THREADS", 512);
     if (wfThreads != 256 && wfThreads != 512 && wfThreads != 1024) wfThreads = 512;
