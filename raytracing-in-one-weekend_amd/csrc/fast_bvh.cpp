@@ -284,7 +284,13 @@ void Scene::buildFastStructure() {
         pad(b);
         prims.push_back(b);
     }
-    if (prims.empty()) return;
+    if (prims.empty()) {
+        // nothing to search: one entry with an inverted box and no leaf run (whatever its test
+        // says, the walk ends without a hit)
+        const float mn[3] = {1.0f, 1.0f, 1.0f}, mx[3] = {-1.0f, -1.0f, -1.0f};
+        Builder{prims, f.fast_nodes, f.fast_refs}.newEntry(mn, mx);
+        return;
+    }
     Builder bld{prims, f.fast_nodes, f.fast_refs};
     bld.build(0, prims.size());
 }

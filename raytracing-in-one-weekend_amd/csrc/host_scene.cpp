@@ -756,6 +756,9 @@ void Scene::flatten() {
     flat.prim_refs.clear();
     flat.max_leaf = 0;
     emitObjects(world, -1);
+    // An empty world (HittableList::Hit over no objects: every ray misses) is one entry without a
+    // box test and without a leaf run, so the walks have something to read.
+    if (flat.nodes.empty()) newEntry(nullptr);
     buildFastStructure();
     flat.valid = true;
 }

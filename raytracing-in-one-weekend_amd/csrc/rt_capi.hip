@@ -385,7 +385,6 @@ int rt_upload_scene(rt_context* ctx, rt_scene* s) {
     HIP_TRY(hipSetDevice(ctx->device));
     rt::Scene& sc = s->sc;
     sc.flatten();
-    if (sc.flat.nodes.empty()) return fail(RT_ERR_STATE, "the world is empty");
     for (const auto& m : sc.materials)
         if (m.kind == RT_MAT_PBR && (m.tex_d < 0 || m.tex_d >= (int)sc.textures.size()))
             return fail(RT_ERR_INVALID, "PBR material without a diffuse texture");
