@@ -196,6 +196,11 @@ int rt_read_accum_rgba32f(rt_context* ctx, float* dst);
 /* writeColor()'s bytes (Raytracer.cpp:22-44): 256 * clamp(sqrt(sum / samples_per_pixel), 0, 0.999),
  * A = 255, row 0 = bottom: the buffer glTexImage2D uploads (RaytracingApplication.cpp:194). */
 int rt_read_rgba8(rt_context* ctx, int samples_per_pixel, uint8_t* dst);
+/* Writes a W*H*4 RGBA8 buffer laid out as rt_read_rgba8() returns it (row 0 = bottom) as a plain
+ * PPM ("P3", 255, top row first, alpha dropped).  Host only; needs no device.  The reference hands
+ * its bytes to glTexImage2D (RaytracingApplication.cpp:194) and has no file writer; this is the
+ * image.ppm of the book the reference follows, for headless use. */
+int rt_write_ppm(const char* path, int width, int height, const uint8_t* rgba8);
 
 /* Device-side resolve of `world` rank payloads laid end to end (the output of an all-gather
  * of every rank's accumulation buffer) into a row-major RGBA32F device image. */

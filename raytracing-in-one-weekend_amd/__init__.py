@@ -85,6 +85,7 @@ SYMBOLS = {
     "rt_run": (_I, [_VP, _I, _I, _I, PASS_CALLBACK, _VP]),
     "rt_read_accum_rgba32f": (_I, [_VP, _VP]),
     "rt_read_rgba8": (_I, [_VP, _I, _VP]),
+    "rt_write_ppm": (_I, [C.c_char_p, _I, _I, _VP]),
     "rt_resolve_gathered": (_I, [_VP, _VP, _I, _VP]),
     "rt_trace": (_I, [_VP, _I] + [_VP] * 7),
     "rt_scatter_test": (_I, [_VP, _I] + [_VP] * 11),
@@ -348,6 +349,14 @@ class Context:
     @property
     def stream(self):
         return lib.rt_stream(self.h)
+
+
+def write_ppm(path, rgba8):
+    """Plain PPM (P3, top row first) of an HxWx4 uint8 image whose row 0 is the bottom row."""
+    a = np.ascontiguousarray(rgba8, dtype=np.uint8)
+    if a.ndim != 3 or a.shape[2] != 4:
+        raise ValueError("expected an HxWx4 uint8 image")
+    _check(lib.rt_write_ppm(os.fsencode(path), a.shape[1], a.shape[0], _p(a)))
 
 
 def accum_bytes(width, height, world=1):

@@ -5,6 +5,7 @@
 
 #include <atomic>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -607,6 +608,29 @@ int rt_read_rgba8(rt_context* ctx, int samples_per_pixel, uint8_t* dst) {
     if (!ctx) return fail(RT_ERR_INVALID, "null context");
     if (samples_per_pixel < 1) return fail(RT_ERR_INVALID, "samples_per_pixel must be positive");
     return readResolved(ctx, 1, samples_per_pixel, dst, (size_t)ctx->width * ctx->height * 4);
+}
+
+int rt_write_ppm(const char* path, int width, int height, const uint8_t* rgba8) {
+    if (!path || !rgba8 || width <= 0 || height <= 0) return fail(RT_ERR_INVALID, "bad arguments");
+    FILE* f = std::fopen(path, "w");
+    if (!f) return fail(RT_ERR_INVALID, std::string("cannot open ") + path);
+    std::fprintf(f, "P3\n%d %d\n255\n", width, height);
+    std::string line;
+    for (int y = height - 1; y >= 0; --y) {  // the buffer's row 0 is the bottom of the image
+        line.clear();
+        for (int x = 0; x < width; ++x) {
+            const uint8_t* p = rgba8 + ((size_t)y * width + x) * 4;
+            char buf[16];
+            int n = std::snprintf(buf, sizeof buf, "%d %d %d\n", (int)p[0], (int)p[1], (int)p[2]);
+            line.append(buf, (size_t)n);
+        }
+        if (std::fwrite(line.data(), 1, line.size(), f) != line.size()) {
+            std::fclose(f);
+            return fail(RT_ERR_INVALID, std::string("short write to ") + path);
+        }
+    }
+    if (std::fclose(f) != 0) return fail(RT_ERR_INVALID, std::string("cannot close ") + path);
+    return RT_OK;
 }
 
 int rt_resolve_gathered(rt_context* ctx, const void* device_payloads, int world, void* device_rgba32f) {

@@ -55,3 +55,18 @@ def test_product_library_does_not_link_the_oracle(rt):
     assert "oracle" not in out
     syms = subprocess.run(["nm", "-D", "--defined-only", rt.LIB_PATH], capture_output=True, text=True).stdout
     assert "orc_" not in syms
+
+
+def test_ppm_writer_round_trip(rt, tmp_path):
+    """P3 header, 255 maximum, top row first (the buffer's row 0 is the bottom row), alpha dropped."""
+    import numpy as np
+    r = np.random.RandomState(0)
+    img = r.randint(0, 256, size=(5, 7, 4)).astype(np.uint8)
+    path = tmp_path / "image.ppm"
+    rt.write_ppm(str(path), img)
+    tok = path.read_text().split()
+    assert tok[:4] == ["P3", "7", "5", "255"]
+    vals = np.array(tok[4:], dtype=np.int64).reshape(5, 7, 3)
+    assert np.array_equal(vals, img[::-1, :, :3])
+    with pytest.raises(rt.RtError):
+        rt.write_ppm(str(tmp_path / "no_such_dir" / "x.ppm"), img)

@@ -198,3 +198,12 @@ def test_error_paths(rt):
         s.add_mesh_gltf(rt.IDENTITY, "/nonexistent/file.gltf", m)
     assert rt.lib.rt_scene_flatten(None, None) < 0
     assert b"null" in rt.lib.rt_last_error()
+
+
+def test_empty_world_flattens_to_one_boxless_entry(rt):
+    """HittableList::Hit over no objects misses every ray; the flattened form is a single entry
+    without a box test and without a leaf run."""
+    s = rt.Scene()
+    d = s.get_flat()
+    assert d["info"].n_nodes == 1 and d["info"].n_prim_refs == 0
+    assert d["nodes"][0, 3] == ((1 << 30) | 1) and d["nodes"][0, 7] == 0xFFFFFFFF
