@@ -18,7 +18,6 @@
 namespace rt {
 hipError_t launchRender(const RenderArgs& a, bool lds, bool count, int blocks, int threads, hipStream_t stream);
 hipError_t launchWavefront(const RenderArgs& a, bool lds, bool count, int blocks, int threads, hipStream_t stream);
-hipError_t launchWavefront2(const RenderArgs& a, bool lds, bool count, int blocks, int threads, hipStream_t stream);
 hipError_t launchTrace(const DevScene& sc, int n, const float* rays, int* kind, int* id, float* t, float* normal,
                        int* front, float* uv, hipStream_t stream);
 hipError_t launchScatter(const DevScene& sc, int n, const int* mat, const float* rayIn, const float* p, const float* nrm,
@@ -156,16 +155,13 @@ int launch(rt_context* ctx, rt::RenderArgs& a, bool count) {
     a.knob[0] = envInt("RT_BOX_KEEP", 4);
     a.knob[1] = envInt("RT_SHADE_MIN", 32);
     int wfThreads = envInt("RT_THREADS", 512);
-    if (wfThreads != 256 && wfThreads != 512 && wfThreads != 768 && wfThreads != 1024) wfThreads = 512;
+    if (wfThreads != 256 && wfThreads != 512 && wfThreads != 1024) wfThreads = 512;
     const int wfWaves = wfThreads / 64;
     blocks = ctx->n_cus * envInt("RT_BLOCKS_PER_CU", 3);
     const int needed = (a.n_local_tiles + wfWaves - 1) / wfWaves;
     if (blocks > needed) blocks = needed;
     if (blocks < 1) blocks = 1;
-    if (kernel && std::strcmp(kernel, "wf2") == 0)
-        HIP_TRY(rt::launchWavefront2(a, ctx->use_lds, count, blocks, wfThreads, ctx->stream));
-    else
-        HIP_TRY(rt::launchWavefront(a, ctx->use_lds, count, blocks, wfThreads, ctx->stream));
+    HIP_TRY(rt::launchWavefront(a, ctx->use_lds, count, blocks, wfThreads, ctx->stream));
     return RT_OK;
 }
 

@@ -943,354 +943,6 @@ __global__ void __launch_bounds__(1024) renderWavefront(RenderArgs a) {
     }
 }
 
-// ---------------------------------------------------------------------------------------
-// Persistent wavefront loop with TWO paths per lane.
-//
-// Same state machine and the same per-path arithmetic as renderWavefront, but every lane
-// carries two independent pixels (A and B).  An operation is voted in when many lanes have a
-// path waiting for it in EITHER slot, and a lane takes part with whichever of its two paths
-// wants the operation.  The pool the scheduler draws from is 128 paths for 64 lanes, so each
-// execution of an operation finds far more lanes to fill than with one path per lane; the
-// price is the select / write-back of the chosen slot's registers around every operation.
-struct PathState {
-    int op, q, px, py, s, depth, idx, p, mode;
-    V3 sum, thr;
-    Rng rng;
-    Ray r;
-    float invx, invy, invz, aa, nox, noy, noz;
-    Hit h;
-};
-
-__device__ __forceinline__ int sel(bool b, int x, int y) { return b ? x : y; }
-__device__ __forceinline__ uint32_t sel(bool b, uint32_t x, uint32_t y) { return b ? x : y; }
-__device__ __forceinline__ float sel(bool b, float x, float y) { return b ? x : y; }
-__device__ __forceinline__ V3 sel(bool b, V3 x, V3 y) { return {b ? x.x : y.x, b ? x.y : y.y, b ? x.z : y.z}; }
-
-// every field of `x` where b, else of `y`
-__device__ __forceinline__ PathState selPath(bool b, const PathState& x, const PathState& y) {
-    PathState w;
-    w.op = sel(b, x.op, y.op); w.q = sel(b, x.q, y.q); w.px = sel(b, x.px, y.px); w.py = sel(b, x.py, y.py);
-    w.s = sel(b, x.s, y.s); w.depth = sel(b, x.depth, y.depth); w.idx = sel(b, x.idx, y.idx); w.p = sel(b, x.p, y.p);
-    w.mode = sel(b, x.mode, y.mode);
-    w.sum = sel(b, x.sum, y.sum); w.thr = sel(b, x.thr, y.thr);
-    w.rng.key = sel(b, x.rng.key, y.rng.key); w.rng.counter = sel(b, x.rng.counter, y.rng.counter);
-    w.r.o = sel(b, x.r.o, y.r.o); w.r.d = sel(b, x.r.d, y.r.d);
-    w.invx = sel(b, x.invx, y.invx); w.invy = sel(b, x.invy, y.invy); w.invz = sel(b, x.invz, y.invz);
-    w.aa = sel(b, x.aa, y.aa);
-    w.nox = sel(b, x.nox, y.nox); w.noy = sel(b, x.noy, y.noy); w.noz = sel(b, x.noz, y.noz);
-    w.h.t = sel(b, x.h.t, y.h.t); w.h.ref = sel(b, x.h.ref, y.h.ref);
-    w.h.bu = sel(b, x.h.bu, y.h.bu); w.h.bv = sel(b, x.h.bv, y.h.bv);
-    return w;
-}
-
-#ifndef WF2_BOUNDS
-#define WF2_BOUNDS 768
-#endif
-template <bool LDS, bool COUNT>
-__global__ void __launch_bounds__(WF2_BOUNDS) renderWavefront2(RenderArgs a) {
-    const DevScene& sc = a.sc;
-    fillCounterLut();
-    SceneView sv;
-    if (LDS) {
-        sv = stageScene(sc);
-    } else {
-        sv = globalView(sc);
-    }
-    const int lane = threadIdx.x & 63;
-    const int nNodesRef = sc.n_nodes, nNodesFast = sc.n_fast_nodes;
-    const int nSlots = a.n_local_tiles * 64;
-    const int sEnd = a.first_sample + a.n_samples;
-    const int boxKeep = a.knob[0];
-    const int shadeMin = a.knob[1];
-    Stats st;
-    if (COUNT)
-        for (int i = 0; i < kNumStats; i++) st.v[i] = 0;
-
-    PathState A;
-    A.op = OP_NEWPIXEL;
-    A.q = A.px = A.py = A.s = A.depth = A.idx = A.p = A.mode = 0;
-    A.sum = V3{0.f, 0.f, 0.f};
-    A.thr = V3{1.f, 1.f, 1.f};
-    A.rng = Rng{0u, 0u};
-    A.r = Ray{{0.f, 0.f, 0.f}, {0.f, 0.f, 1.f}};
-    A.invx = A.invy = A.invz = 0.f;
-    A.aa = 1.f;
-    A.nox = A.noy = A.noz = 0.f;
-    A.h = Hit{0.f, kNoHit, 0.f, 0.f};
-    PathState B = A;
-
-    int poolNext = 0, poolEnd = 0;
-    unsigned long long schedExec[7] = {0, 0, 0, 0, 0, 0, 0}, schedLanes[7] = {0, 0, 0, 0, 0, 0, 0};
-
-    auto startRay = [&](PathState& w) {
-        w.invx = 1.0f / w.r.d.x;
-        w.invy = 1.0f / w.r.d.y;
-        w.invz = 1.0f / w.r.d.z;
-        w.aa = dot(w.r.d, w.r.d);
-        w.h.t = __builtin_inff();
-        w.h.ref = kNoHit;
-        w.idx = 0;
-        w.nox = -(w.r.o.x * w.invx);
-        w.noy = -(w.r.o.y * w.invy);
-        w.noz = -(w.r.o.z * w.invz);
-        w.mode = (sc.force_ref || !fastTestUsable(w.invx, w.invy, w.invz, w.nox, w.noy, w.noz)) ? 1 : 0;
-        w.op = w.mode ? OP_REFBOX : OP_BOX;
-        if (COUNT) st.v[C_RAYS]++;
-    };
-    auto retraceInReferenceOrder = [&](PathState& w) {
-        w.h.t = __builtin_inff();
-        w.h.ref = kNoHit;
-        w.idx = 0;
-        w.op = OP_REFBOX;
-        w.mode = 1;
-        if (COUNT) st.v[C_FALLBACK]++;
-    };
-    auto endPath = [&](PathState& w, V3 terminal) {
-        V3 c = w.thr * terminal;
-        w.sum = w.sum + c;
-        w.s += 1;
-        w.op = OP_NEWPATH;
-    };
-    // NEWPIXEL for one slot: hand the waiting lanes the next pixel slots, in lane order
-    auto assignPixels = [&](PathState& w) {
-        const bool want = w.op == OP_NEWPIXEL;
-        const unsigned long long m = __ballot(want);
-        const int need = popc64(m);
-        if (need == 0) return;
-        if (poolEnd >= 0 && poolNext >= poolEnd) {  // pool used up: pull the next 64 slots
-            unsigned int base = 0;
-            if (lane == 0) base = atomicAdd(a.queue, 64u);
-            base = __builtin_amdgcn_readfirstlane(base);
-            if (base >= (unsigned int)nSlots) {
-                poolNext = poolEnd = -1;  // the queue is dry
-            } else {
-                poolNext = (int)base;
-                poolEnd = (int)base + 64 < nSlots ? (int)base + 64 : nSlots;
-            }
-        }
-        const int avail = poolEnd < 0 ? 0 : poolEnd - poolNext;
-        if (want) {
-            const int rankInMask = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-            if (poolEnd < 0) {
-                w.op = OP_DONE;
-            } else if (rankInMask < avail) {
-                w.q = poolNext + rankInMask;
-                const int tile = w.q >> 6, l = w.q & 63;
-                const int ty = tile / a.tiles_per_row_local;
-                const int k = tile - ty * a.tiles_per_row_local;
-                int base = (a.rank - ty) % a.world;
-                if (base < 0) base += a.world;
-                const int tx = base + k * a.world;
-                w.px = tx * kTile + (l & 7);
-                w.py = ty * kTile + (l >> 3);
-                if (tx < a.tiles_x && w.px < a.width && w.py < a.height) {
-                    const float4 acc = a.accum[w.q];
-                    w.sum = V3{acc.x, acc.y, acc.z};
-                    w.s = a.first_sample;
-                    w.op = OP_NEWPATH;
-                }  // else a padding slot outside the image: this path asks again
-            }      // else the pool ran out before this lane's turn: it asks again
-        }
-        poolNext += need < avail ? need : avail;
-    };
-
-    for (;;) {
-        const int oa = A.op, ob = B.op;
-        const int cBox = popc64(__ballot(oa == OP_BOX || ob == OP_BOX));
-        const int cPrim = popc64(__ballot(oa == OP_PRIM || ob == OP_PRIM));
-        const int cShade = popc64(__ballot(oa == OP_SHADE || ob == OP_SHADE));
-        const int cPath = popc64(__ballot(oa == OP_NEWPATH || ob == OP_NEWPATH));
-        const int cPixel = popc64(__ballot(oa == OP_NEWPIXEL || ob == OP_NEWPIXEL));
-        const int cRef = popc64(__ballot(oa == OP_REFBOX || ob == OP_REFBOX));
-        if ((cBox | cPrim | cShade | cPath | cPixel | cRef) == 0) break;
-
-        int chosen;
-        if (cPixel > 0 && (cPixel >= 16 || (cBox | cPrim | cShade | cPath | cRef) == 0)) {
-            chosen = OP_NEWPIXEL;
-        } else if (cShade >= shadeMin || cPath >= shadeMin) {
-            chosen = cShade >= cPath ? OP_SHADE : OP_NEWPATH;
-        } else {
-            chosen = OP_BOX;
-            int best = cBox;
-            if (cRef > best) { best = cRef; chosen = OP_REFBOX; }
-            if (cPrim > best) { best = cPrim; chosen = OP_PRIM; }
-            if (cShade > best) { best = cShade; chosen = OP_SHADE; }
-            if (cPath > best) { best = cPath; chosen = OP_NEWPATH; }
-            if (best == 0) chosen = OP_NEWPIXEL;
-        }
-        if (COUNT) {
-            const int cnt[6] = {cBox, cPrim, cShade, cPath, cPixel, cRef};
-            const int slot = chosen == OP_REFBOX ? 6 : chosen;
-            schedExec[slot] += 1;
-            schedLanes[slot] += cnt[chosen];
-        }
-        // which slot of this lane takes part: A if it wants the operation, else B if it does
-        const bool useA = oa == chosen;
-        const bool useB = !useA && ob == chosen;
-        const bool act = useA || useB;
-
-        if (chosen == OP_BOX) {
-            int idx = sel(useB, B.idx, A.idx), p = sel(useB, B.p, A.p);
-            const float invx = sel(useB, B.invx, A.invx), invy = sel(useB, B.invy, A.invy), invz = sel(useB, B.invz, A.invz);
-            const float nox = sel(useB, B.nox, A.nox), noy = sel(useB, B.noy, A.noy), noz = sel(useB, B.noz, A.noz);
-            const float ht = sel(useB, B.h.t, A.h.t);
-            int op = act ? OP_BOX : OP_DONE;
-            const int keep = boxKeep < cBox ? boxKeep : cBox;
-            do {
-                if (COUNT) {
-                    schedExec[5] += 1;
-                    schedLanes[5] += popc64(__ballot(op == OP_BOX));
-                }
-                if (op == OP_BOX) {
-                    const float4 n0 = sv.fnodes[2 * idx], n1 = sv.fnodes[2 * idx + 1];
-                    const int first = (int)fbits(n1.w);
-                    if (COUNT) st.v[C_NODE]++;
-                    const bool pass = slabPassFast(n0, n1, invx, invy, invz, nox, noy, noz, ht);
-                    idx = pass ? idx + 1 : (int)fbits(n1.z);
-                    if (pass && first >= 0) {
-                        p = first;
-                        op = OP_PRIM;
-                    } else if (idx >= nNodesFast) {
-                        op = OP_SHADE;
-                    }
-                }
-            } while (popc64(__ballot(op == OP_BOX)) >= keep && keep > 0);
-            if (useA) { A.idx = idx; A.p = p; A.op = op; }
-            if (useB) { B.idx = idx; B.p = p; B.op = op; }
-        } else if (chosen == OP_REFBOX) {
-            int idx = sel(useB, B.idx, A.idx), p = sel(useB, B.p, A.p);
-            const Ray r{sel(useB, B.r.o, A.r.o), sel(useB, B.r.d, A.r.d)};
-            const float invx = sel(useB, B.invx, A.invx), invy = sel(useB, B.invy, A.invy), invz = sel(useB, B.invz, A.invz);
-            const float ht = sel(useB, B.h.t, A.h.t);
-            int op = act ? OP_REFBOX : OP_DONE;
-            const int keep = boxKeep < cRef ? boxKeep : cRef;
-            do {
-                if (COUNT) {
-                    schedExec[5] += 1;
-                    schedLanes[5] += popc64(__ballot(op == OP_REFBOX));
-                }
-                if (op == OP_REFBOX) {
-                    const float4 n0 = sv.nodes[2 * idx], n1 = sv.nodes[2 * idx + 1];
-                    const uint32_t w3 = fbits(n0.w);
-                    const int first = (int)fbits(n1.w);
-                    const bool nobox = (w3 & kNoBox) != 0;
-                    if (COUNT && !nobox) st.v[C_NODE]++;
-                    const bool pass = slabPass(n0, n1, r, invx, invy, invz, ht) || nobox;
-                    idx = pass ? idx + 1 : (int)(w3 & kSkipMask);
-                    if (pass && first >= 0) {
-                        p = first;
-                        op = OP_PRIM;
-                    } else if (idx >= nNodesRef) {
-                        op = OP_SHADE;
-                    }
-                }
-            } while (popc64(__ballot(op == OP_REFBOX)) >= keep && keep > 0);
-            if (useA) { A.idx = idx; A.p = p; A.op = op; }
-            if (useB) { B.idx = idx; B.p = p; B.op = op; }
-        } else if (chosen == OP_PRIM) {
-            int idx = sel(useB, B.idx, A.idx), p = sel(useB, B.p, A.p), mode = sel(useB, B.mode, A.mode);
-            const Ray r{sel(useB, B.r.o, A.r.o), sel(useB, B.r.d, A.r.d)};
-            const float aa = sel(useB, B.aa, A.aa);
-            Hit h{sel(useB, B.h.t, A.h.t), sel(useB, B.h.ref, A.h.ref), sel(useB, B.h.bu, A.h.bu), sel(useB, B.h.bv, A.h.bv)};
-            int op = OP_PRIM;
-            if (act) {
-                const uint32_t ref = (mode ? sv.refs : sv.frefs)[p];
-                bool bad = false;
-                if (mode) {
-                    primRef<COUNT>(sv, ref, r, aa, h, &st);
-                } else {
-                    primAnyOrder<COUNT>(sv, ref, r, aa, h, bad, &st);
-                }
-                if (bad) {
-                    h.t = __builtin_inff();
-                    h.ref = kNoHit;
-                    idx = 0;
-                    op = OP_REFBOX;
-                    mode = 1;
-                    if (COUNT) st.v[C_FALLBACK]++;
-                } else if (ref & kRefLast) {
-                    op = idx >= (mode ? nNodesRef : nNodesFast) ? OP_SHADE : (mode ? OP_REFBOX : OP_BOX);
-                } else {
-                    p += 1;
-                }
-            }
-            if (useA) { A.idx = idx; A.p = p; A.mode = mode; A.h = h; A.op = op; }
-            if (useB) { B.idx = idx; B.p = p; B.mode = mode; B.h = h; B.op = op; }
-        } else if (chosen == OP_SHADE) {
-            PathState w = selPath(useB, B, A);
-            if (act) {
-                if (w.h.ref == kNoHit) {
-                    if (COUNT) st.v[C_MISS]++;
-                    endPath(w, V3{sc.bg[0], sc.bg[1], sc.bg[2]});
-                } else if (w.mode == 0 && !guardsPass<COUNT>(sv, w.r, w.invx, w.invy, w.invz, w.h, &st)) {
-                    retraceInReferenceOrder(w);
-                } else {
-                    if (COUNT) st.v[C_HITS]++;
-                    Surface sf = surfaceAt(sc, sv, w.r, w.h);
-                    Ray out;
-                    V3 atten, emit;
-                    if (!scatter<COUNT>(sc, sv, w.r, sf, w.rng, out, atten, emit, &st)) {
-                        endPath(w, emit);
-                    } else {
-                        w.thr = w.thr * atten;
-                        w.r = out;
-                        w.depth -= 1;
-                        if (w.depth <= 0) {
-                            if (COUNT) st.v[C_CUTOFF]++;
-                            endPath(w, V3{0.0f, 0.0f, 0.0f});
-                        } else {
-                            startRay(w);
-                        }
-                    }
-                }
-            }
-            if (useA) A = w;
-            if (useB) B = w;
-        } else if (chosen == OP_NEWPATH) {
-            PathState w = selPath(useB, B, A);
-            if (act) {
-                if (w.s >= sEnd) {
-                    a.accum[w.q] = make_float4(w.sum.x, w.sum.y, w.sum.z, (float)sEnd);
-                    w.op = OP_NEWPIXEL;
-                } else {
-                    w.rng.init((uint32_t)w.px, (uint32_t)w.py, w.s);
-                    if (COUNT) st.v[C_SAMPLES]++;
-                    // u is drawn before v (R/src/Core/Raytracer.cpp:86-87)
-                    float u = ((float)w.px + w.rng.next()) / (float)(a.width - 1);
-                    float v = ((float)w.py + w.rng.next()) / (float)(a.height - 1);
-                    w.r = cameraRay(sc, u, v, w.rng);
-                    w.thr = V3{1.0f, 1.0f, 1.0f};
-                    w.depth = a.max_depth;
-                    if (w.depth <= 0) {
-                        if (COUNT) st.v[C_CUTOFF]++;
-                        endPath(w, V3{0.0f, 0.0f, 0.0f});
-                    } else {
-                        startRay(w);
-                    }
-                }
-            }
-            if (useA) A = w;
-            if (useB) B = w;
-        } else {  // OP_NEWPIXEL, slot A first
-            assignPixels(A);
-            assignPixels(B);
-        }
-    }
-    if (COUNT && lane == 0) {
-        for (int i = 0; i < 7; i++) {
-            atomicAdd(&a.counters[13 + 2 * i], schedExec[i]);
-            atomicAdd(&a.counters[14 + 2 * i], schedLanes[i]);
-        }
-    }
-    if (COUNT) {
-        for (int i = 0; i < kNumStats; i++) {
-            unsigned long long v = st.v[i];
-            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-            if (lane == 0 && v) atomicAdd(&a.counters[i < 13 ? i : 27], v);
-        }
-    }
-}
-
 // Closest hit + hit record of arbitrary rays (test hook behind rt_trace).
 __global__ void __launch_bounds__(256) traceKernel(DevScene sc, int n, const float* rays, int* kind, int* id, float* t,
                                                    float* normal, int* front, float* uv) {
@@ -1408,23 +1060,6 @@ hipError_t launchWavefront(const RenderArgs& a, bool lds, bool count, int blocks
                           : launchWavefrontT<true, false>(a, blocks, threads, shmem, stream);
     return count ? launchWavefrontT<false, true>(a, blocks, threads, 0, stream)
                  : launchWavefrontT<false, false>(a, blocks, threads, 0, stream);
-}
-
-template <bool LDS, bool COUNT>
-static hipError_t launchWavefront2T(const RenderArgs& a, int blocks, int threads, size_t shmem, hipStream_t stream) {
-    if (LDS)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(renderWavefront2<LDS, COUNT>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    renderWavefront2<LDS, COUNT><<<blocks, threads, shmem, stream>>>(a);
-    return hipGetLastError();
-}
-
-hipError_t launchWavefront2(const RenderArgs& a, bool lds, bool count, int blocks, int threads, hipStream_t stream) {
-    size_t shmem = lds ? (size_t)a.lds_bytes : 0;
-    if (lds) return count ? launchWavefront2T<true, true>(a, blocks, threads, shmem, stream)
-                          : launchWavefront2T<true, false>(a, blocks, threads, shmem, stream);
-    return count ? launchWavefront2T<false, true>(a, blocks, threads, 0, stream)
-                 : launchWavefront2T<false, false>(a, blocks, threads, 0, stream);
 }
 
 hipError_t launchRender(const RenderArgs& a, bool lds, bool count, int blocks, int threads, hipStream_t stream) {
