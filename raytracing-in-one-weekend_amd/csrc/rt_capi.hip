@@ -155,9 +155,11 @@ int launch(rt_context* ctx, rt::RenderArgs& a, bool count) {
     a.knob[0] = envInt("RT_BOX_KEEP", 4);
     a.knob[1] = envInt("RT_SHADE_MIN", 32);
     int wfThreads = envInt("RT_THREADS", 512);
-    if (wfThreads != 256 && wfThreads != 512 && wfThreads != 1024) wfThreads = 512;
+    if (wfThreads < 64 || wfThreads > 1024 || wfThreads % 64 != 0) wfThreads = 512;
     const int wfWaves = wfThreads / 64;
-    blocks = ctx->n_cus * envInt("RT_BLOCKS_PER_CU", 3);
+    // two 512-thread workgroups per CU = 4 waves per SIMD: measured best (a scene staged in LDS
+    // leaves room for two workgroups; more waves per SIMD ran slower, fewer too)
+    blocks = ctx->n_cus * envInt("RT_BLOCKS_PER_CU", 2);
     const int needed = (a.n_local_tiles + wfWaves - 1) / wfWaves;
     if (blocks > needed) blocks = needed;
     if (blocks < 1) blocks = 1;

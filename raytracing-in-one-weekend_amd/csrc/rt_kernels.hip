@@ -431,6 +431,9 @@ __device__ __forceinline__ bool scatter(const DevScene& sc, const SceneView& sv,
     // it, so the rejection loop runs once for all the lanes of a wave, whatever their material.
     V3 ball{0.0f, 0.0f, 0.0f};
     if (kind == 0 || kind == 1 || kind == 4) ball = randomInUnitSphere(rng);
+    // likewise glm::normalize(rayIn.direction) of Metal, Dielectric and PBR
+    V3 unitIn{0.0f, 0.0f, 0.0f};
+    if (kind == 1 || kind == 2 || kind == 4) unitIn = normalize(in.d);
     if (kind == 0) {  // Lambertian, Material.h:22-36
         if (COUNT) st->v[C_LAMB]++;
         V3 dir = s.n + normalize(ball);
@@ -442,7 +445,7 @@ __device__ __forceinline__ bool scatter(const DevScene& sc, const SceneView& sv,
     }
     if (kind == 1) {  // Metal, Material.h:47-53
         if (COUNT) st->v[C_METAL]++;
-        V3 reflected = reflect(normalize(in.d), s.n);
+        V3 reflected = reflect(unitIn, s.n);
         out.d = reflected + m0.w * ball;
         atten = {m0.x, m0.y, m0.z};
         return dot(out.d, s.n) > 0;
@@ -452,7 +455,7 @@ __device__ __forceinline__ bool scatter(const DevScene& sc, const SceneView& sv,
         atten = {1.0f, 1.0f, 1.0f};
         const float ir = m0.w;
         float ratio = s.front ? (1.0f / ir) : ir;
-        V3 unit = normalize(in.d);
+        V3 unit = unitIn;
         float cosTheta = fminf(dot(-unit, s.n), 1.0f);
         float sinTheta = sqrtf(1.0f - cosTheta * cosTheta);
         bool reflectIt = ratio * sinTheta > 1.0f;
@@ -487,7 +490,7 @@ __device__ __forceinline__ bool scatter(const DevScene& sc, const SceneView& sv,
     const int texD = (int)fbits(m1.y), texR = (int)fbits(m1.z);
     atten = textureAt(sc, texD, s.u, s.v);
     if (texR >= 0) {
-        V3 reflected = reflect(normalize(in.d), s.n);
+        V3 reflected = reflect(unitIn, s.n);
         V3 rough = textureAt(sc, texR, s.u, s.v);
         out.d = reflected + rough * ball;
         return dot(out.d, s.n) > 0;
