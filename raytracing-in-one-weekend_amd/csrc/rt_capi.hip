@@ -42,6 +42,7 @@ struct rt_context {
     bool scene_loaded = false;
     size_t lds_need = 0;
     bool use_lds = false;
+    bool lds_refs = true;  // the reference-order arrays are staged too
     int n_cus = 256;
     int width = 0, height = 0, rank = 0, world = 1;
     int tiles_x = 0, tiles_y = 0, tprl = 0, n_local_tiles = 0;
@@ -125,6 +126,7 @@ rt::RenderArgs makeArgs(rt_context* ctx, int first_sample, int n_samples, int ma
     a.n_samples = n_samples;
     a.max_depth = max_depth;
     a.lds_bytes = (int)ctx->lds_need;
+    a.knob[2] = ctx->lds_refs ? 1 : 0;
     return a;
 }
 
@@ -482,8 +484,13 @@ int rt_upload_scene(rt_context* ctx, rt_scene* s) {
     std::memcpy(d.cam, &sc.camera, sizeof(float) * 22);
     std::memcpy(d.bg, sc.background, sizeof(float) * 3);
     ctx->dsc = d;
-    ctx->lds_need = rt::ldsSceneBytes(d);
-    ctx->use_lds = ctx->lds_need <= kMaxLdsScene && envInt("RT_LDS", 1) != 0;
+    // Scene tables in LDS when they fit: all of them, else all but the reference-order arrays
+    // (measured equally fast: those are touched once or twice per accepted hit), else none.
+    // RT_LDS overrides: 0 = global memory, 1 = all tables or nothing, 2 = without the reference arrays.
+    const int ldsMode = envInt("RT_LDS", -1);
+    ctx->lds_refs = ldsMode == 1 || (ldsMode < 0 && rt::ldsSceneBytes(d, true) <= kMaxLdsScene);
+    ctx->lds_need = rt::ldsSceneBytes(d, ctx->lds_refs);
+    ctx->use_lds = ctx->lds_need <= kMaxLdsScene && ldsMode != 0;
     ctx->scene_loaded = true;
     return RT_OK;
 }

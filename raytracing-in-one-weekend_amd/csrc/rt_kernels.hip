@@ -555,7 +555,7 @@ __device__ __forceinline__ V3 rayColor(const DevScene& sc, const SceneView& sv, 
 extern __shared__ float4 rt_lds[];
 
 // Stages the scene tables into LDS and returns views into it (layout = ldsSceneBytes()).
-__device__ __forceinline__ SceneView stageScene(const DevScene& sc) {
+__device__ __forceinline__ SceneView stageScene(const DevScene& sc, bool withReferenceArrays) {
     char* base = reinterpret_cast<char*>(rt_lds);
     int off = 0;
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -571,20 +571,30 @@ __device__ __forceinline__ SceneView stageScene(const DevScene& sc) {
         for (int i = tid; i < n; i += nt) dst[i] = src[i];
         return dst;
     };
+    auto take4i = [&](const int* src, int n) {
+        return reinterpret_cast<const int*>(take4(reinterpret_cast<const uint32_t*>(src), n));
+    };
     SceneView v;
-    v.nodes = take16(sc.nodes, sc.n_nodes * 2);
-    v.refs = take4(sc.prim_refs, sc.n_prim_refs);
     v.fnodes = take16(sc.fast_nodes, sc.n_fast_nodes * 2);
     v.frefs = take4(sc.fast_refs, sc.n_fast_refs);
     v.spheres = take16(sc.spheres, sc.n_spheres);
     v.tris = take16(sc.tri_isect, sc.n_tris * 3);
-    v.sphere_mat = reinterpret_cast<const int*>(take4(reinterpret_cast<const uint32_t*>(sc.sphere_mat), sc.n_spheres));
-    v.tri_mat = reinterpret_cast<const int*>(take4(reinterpret_cast<const uint32_t*>(sc.tri_mat), sc.n_tris));
+    v.sphere_mat = take4i(sc.sphere_mat, sc.n_spheres);
+    v.tri_mat = take4i(sc.tri_mat, sc.n_tris);
     v.materials = take16(sc.materials, sc.n_mats * 2);
-    v.sphere_ord = reinterpret_cast<const int*>(take4(reinterpret_cast<const uint32_t*>(sc.sphere_ord), sc.n_spheres));
-    v.tri_ord = reinterpret_cast<const int*>(take4(reinterpret_cast<const uint32_t*>(sc.tri_ord), sc.n_tris));
-    v.prim_guard = reinterpret_cast<const int*>(take4(reinterpret_cast<const uint32_t*>(sc.prim_guard), sc.n_prim_refs));
-    v.node_outer = reinterpret_cast<const int*>(take4(reinterpret_cast<const uint32_t*>(sc.node_outer), sc.n_nodes));
+    v.sphere_ord = take4i(sc.sphere_ord, sc.n_spheres);
+    v.tri_ord = take4i(sc.tri_ord, sc.n_tris);
+    if (withReferenceArrays) {
+        v.nodes = take16(sc.nodes, sc.n_nodes * 2);
+        v.refs = take4(sc.prim_refs, sc.n_prim_refs);
+        v.prim_guard = take4i(sc.prim_guard, sc.n_prim_refs);
+        v.node_outer = take4i(sc.node_outer, sc.n_nodes);
+    } else {
+        v.nodes = sc.nodes;
+        v.refs = sc.prim_refs;
+        v.prim_guard = sc.prim_guard;
+        v.node_outer = sc.node_outer;
+    }
     __syncthreads();
     return v;
 }
@@ -598,7 +608,7 @@ __global__ void __launch_bounds__(256) renderKernel(RenderArgs a) {
     fillCounterLut();
     SceneView sv;
     if (LDS) {
-        sv = stageScene(sc);
+        sv = stageScene(sc, a.knob[2] != 0);
     } else {
         sv = globalView(sc);
     }
@@ -674,13 +684,16 @@ enum : int { OP_BOX = 0, OP_PRIM = 1, OP_SHADE = 2, OP_NEWPATH = 3, OP_NEWPIXEL 
 
 __device__ __forceinline__ int popc64(unsigned long long m) { return __builtin_popcountll(m); }
 
+#ifndef WF_BOUNDS
+#define WF_BOUNDS 1024
+#endif
 template <bool LDS, bool COUNT>
-__global__ void __launch_bounds__(1024) renderWavefront(RenderArgs a) {
+__global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
     const DevScene& sc = a.sc;
     fillCounterLut();
     SceneView sv;
     if (LDS) {
-        sv = stageScene(sc);
+        sv = stageScene(sc, a.knob[2] != 0);
     } else {
         sv = globalView(sc);
     }
