@@ -3,7 +3,6 @@
 // when the HIP runtime cannot run the kernels.
 #include <hip/hip_runtime.h>
 
-#include <algorithm>
 #include <atomic>
 #include <cmath>
 #include <cstdio>
@@ -19,10 +18,6 @@
 namespace rt {
 hipError_t launchRender(const RenderArgs& a, bool lds, bool count, int blocks, int threads, hipStream_t stream);
 hipError_t launchWavefront(const RenderArgs& a, bool lds, bool count, int blocks, int threads, hipStream_t stream);
-hipError_t launchPoolReset(const PathPool& pl, int n_iter_counters, hipStream_t stream);
-hipError_t launchPoolShade(const RenderArgs& a, bool count, hipStream_t stream);
-hipError_t launchPoolTrace(const RenderArgs& a, bool lds, bool count, int blocks, int threads, hipStream_t stream);
-hipError_t launchPoolResolve(const RenderArgs& a, int n_samples, hipStream_t stream);
 hipError_t launchTrace(const DevScene& sc, int n, const float* rays, int* kind, int* id, float* t, float* normal,
                        int* front, float* uv, hipStream_t stream);
 hipError_t launchScatter(const DevScene& sc, int n, const int* mat, const float* rayIn, const float* p, const float* nrm,
@@ -59,12 +54,6 @@ struct rt_context {
     int force_ref = 0;
     bool huge_coords = false;
     unsigned long long sched_stats[14] = {0};  // from the last rt_count(): {executions, lanes} per operation
-    // path pool of the two-kernel pipeline (allocated on first use, grown on demand)
-    rt::PathPool pool{};
-    size_t pool_paths_cap = 0, pool_items_cap = 0;
-    unsigned int* emitted_host = nullptr;  // pinned
-    hipEvent_t batch_ev[2] = {nullptr, nullptr};
-    int last_iterations = 0;
 };
 
 namespace {
@@ -105,51 +94,6 @@ void freeScene(rt_context* ctx) {
     for (void* p : ctx->scene_allocs) (void)hipFree(p);
     ctx->scene_allocs.clear();
     ctx->scene_loaded = false;
-}
-
-constexpr int kMaxPoolIterations = 8192;
-
-void freePool(rt_context* ctx) {
-    rt::PathPool& p = ctx->pool;
-    void* ptrs[] = {p.ray_o, p.ray_d, p.hit, p.thr_k, p.misc, p.colors, p.next_item, p.emitted};
-    for (void* q : ptrs)
-        if (q) (void)hipFree(q);
-    p = rt::PathPool{};
-    ctx->pool_paths_cap = ctx->pool_items_cap = 0;
-    if (ctx->emitted_host) (void)hipHostFree(ctx->emitted_host);
-    ctx->emitted_host = nullptr;
-    for (auto& e : ctx->batch_ev) {
-        if (e) (void)hipEventDestroy(e);
-        e = nullptr;
-    }
-}
-
-int ensurePool(rt_context* ctx, size_t paths, size_t items) {
-    rt::PathPool& p = ctx->pool;
-    if (!p.next_item) {
-        HIP_TRY(hipMalloc((void**)&p.next_item, 256));
-        HIP_TRY(hipMalloc((void**)&p.emitted, kMaxPoolIterations * sizeof(unsigned int)));
-        HIP_TRY(hipHostMalloc((void**)&ctx->emitted_host, kMaxPoolIterations * sizeof(unsigned int)));
-        for (auto& e : ctx->batch_ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    }
-    if (paths > ctx->pool_paths_cap) {
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
-        void** arrs[] = {(void**)&p.ray_o, (void**)&p.ray_d, (void**)&p.hit, (void**)&p.thr_k, (void**)&p.misc};
-        for (void** a : arrs) {
-            if (*a) (void)hipFree(*a);
-            *a = nullptr;
-            HIP_TRY(hipMalloc(a, paths * 16));
-        }
-        ctx->pool_paths_cap = paths;
-    }
-    if (items > ctx->pool_items_cap) {
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
-        if (p.colors) (void)hipFree(p.colors);
-        p.colors = nullptr;
-        HIP_TRY(hipMalloc((void**)&p.colors, items * 16));
-        ctx->pool_items_cap = items;
-    }
-    return RT_OK;
 }
 
 void freeTarget(rt_context* ctx) {
@@ -193,58 +137,6 @@ int checkRenderState(rt_context* ctx) {
     return RT_OK;
 }
 
-// The two-kernel pipeline: shade and trace passes over a pool of paths in HBM, alternated until a
-// shade pass emits no ray, then the ordered per-pixel sum.  The host looks at the emitted-ray
-// count one batch of iterations behind the one it is enqueuing, so the stream never drains.
-int renderPool(rt_context* ctx, rt::RenderArgs a, bool count) {
-    const size_t nSlots = (size_t)a.n_local_tiles * 64;
-    const int first = a.first_sample, total = a.n_samples;
-    const size_t colorsBudget = (size_t)envInt("RT_POOL_COLORS_MB", 4096) << 20;
-    int chunk = (int)std::min<size_t>((size_t)total, std::max<size_t>(1, colorsBudget / (nSlots * 16)));
-    const size_t wantPaths = (size_t)envInt("RT_POOL_PATHS", 4 << 20);
-    const int batch = std::max(1, envInt("RT_POOL_BATCH", 8));
-    int wfThreads = envInt("RT_THREADS", 512);
-    if (wfThreads < 64 || wfThreads > 1024 || wfThreads % 64 != 0) wfThreads = 512;
-    const int traceBlocks = ctx->n_cus * envInt("RT_BLOCKS_PER_CU", 2);
-    a.knob[0] = envInt("RT_BOX_KEEP", 4);
-    a.knob[3] = envInt("RT_NEXT_MIN", 16);
-    ctx->last_iterations = 0;
-    for (int s0 = 0; s0 < total; s0 += chunk) {
-        const int ns = std::min(chunk, total - s0);
-        const size_t items = nSlots * (size_t)ns;
-        if (items >= (size_t)0xFFFFFFFFu - (64u << 20)) return fail(RT_ERR_LIMIT, "too many samples in one pass");
-        const size_t paths = std::min(wantPaths, items);
-        int rc = ensurePool(ctx, paths, items);
-        if (rc) return rc;
-        a.first_sample = first + s0;
-        a.n_samples = ns;
-        a.pool = ctx->pool;
-        a.pool.n_paths = (int)paths;
-        a.pool.n_items = (unsigned int)items;
-        HIP_TRY(rt::launchPoolReset(a.pool, kMaxPoolIterations, ctx->stream));
-        bool finished = false;
-        int it = 0;
-        for (int b = 0; !finished; b++) {
-            if (it + batch > kMaxPoolIterations) return fail(RT_ERR_LIMIT, "path pool did not drain");
-            for (int j = 0; j < batch; j++, it++) {
-                a.iter = it;
-                HIP_TRY(rt::launchPoolShade(a, count, ctx->stream));
-                HIP_TRY(rt::launchPoolTrace(a, ctx->use_lds, count, traceBlocks, wfThreads, ctx->stream));
-            }
-            HIP_TRY(hipMemcpyAsync(ctx->emitted_host + b % kMaxPoolIterations, a.pool.emitted + (it - 1), sizeof(unsigned int),
-                                   hipMemcpyDeviceToHost, ctx->stream));
-            HIP_TRY(hipEventRecord(ctx->batch_ev[b & 1], ctx->stream));
-            if (b >= 1) {
-                HIP_TRY(hipEventSynchronize(ctx->batch_ev[(b - 1) & 1]));
-                finished = ctx->emitted_host[(b - 1) % kMaxPoolIterations] == 0;
-            }
-        }
-        ctx->last_iterations += it;
-        HIP_TRY(rt::launchPoolResolve(a, ns, ctx->stream));
-    }
-    return RT_OK;
-}
-
 // Launch shape.  Default: the persistent wavefront loop, a fixed number of 256-thread
 // workgroups per CU that pull pixels from a queue.  RT_KERNEL=simple selects the plain
 // one-wave-per-tile kernel (kept for A/B measurements); both produce identical images.
@@ -253,7 +145,6 @@ int launch(rt_context* ctx, rt::RenderArgs& a, bool count) {
     const int wavesPerBlock = threads / 64;
     const char* kernel = std::getenv("RT_KERNEL");
     const bool simple = kernel && std::strcmp(kernel, "simple") == 0;
-    if (kernel && std::strcmp(kernel, "pool") == 0) return renderPool(ctx, a, count);
     int blocks;
     if (simple) {
         blocks = (a.n_local_tiles + wavesPerBlock - 1) / wavesPerBlock;
@@ -471,7 +362,6 @@ void rt_destroy(rt_context* ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     freeScene(ctx);
     freeTarget(ctx);
-    freePool(ctx);
     if (ctx->queue) (void)hipFree(ctx->queue);
     if (ctx->counters) (void)hipFree(ctx->counters);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);

@@ -34,25 +34,6 @@ struct DevScene {
     float bg[3];
 };
 
-// Path pool of the two-kernel pipeline (poolShade / poolTrace): `n_paths` slots, each holding one
-// path in flight.  A work item is one pixel sample: item k = s_local * n_slots + q (s_local =
-// sample index relative to the launch's first sample, q = pixel slot of the tiled accumulation
-// buffer), handed out in order from `next_item`; its radiance goes to colors[k] and a final
-// kernel adds every pixel's items in sample order into the accumulation buffer.
-struct PathPool {
-    float4* ray_o;    // {origin.xyz, 1.0f while a ray waits to be traced / 0}
-    float4* ray_d;    // {direction.xyz, -}
-    float4* hit;      // {t, leaf reference (bits), barycentric u, v}
-    float4* thr_k;    // {throughput.xyz, item k (bits)}
-    uint4* misc;      // {rng key, rng counter, remaining depth, phase}
-    float4* colors;   // one per work item
-    unsigned int* next_item;
-    unsigned int* emitted;  // [iteration]: rays emitted by that iteration's shade pass
-    int n_paths;
-    unsigned int n_items;   // n_slots * samples of this launch
-};
-enum : unsigned { PH_DONE = 0, PH_IDLE = 1, PH_TRACED = 2 };
-
 struct RenderArgs {
     DevScene sc;
     float4* accum;        // tiled: [local tile][lane] -> {r, g, b, samples}
@@ -66,8 +47,6 @@ struct RenderArgs {
     int first_sample, n_samples, max_depth;
     int lds_bytes;
     int knob[4];  // scheduling thresholds of the wavefront loop (never affect results)
-    PathPool pool;
-    int iter;     // iteration of the two-kernel pipeline
 };
 
 constexpr int kTile = 8;  // one wave64 = one 8x8 pixel tile

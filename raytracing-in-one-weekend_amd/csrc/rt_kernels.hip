@@ -959,397 +959,6 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
     }
 }
 
-// ---------------------------------------------------------------------------------------
-// Two-kernel pipeline over a pool of paths in HBM.
-//
-// poolShade (one thread per pool slot, every lane busy): consumes the slot's hit record --
-// Material::scatter, or the end of the path, whose radiance goes to colors[item] -- and
-// leaves the slot with the next ray to trace: the scattered ray, or the camera ray of the
-// next work item (pixel sample) taken from the launch-wide queue.  poolTrace (persistent
-// waves, BOX / PRIM state machine as in renderWavefront but with nothing else competing for
-// the lanes) finds the closest hit of every pending ray.  The host alternates the two until
-// no ray is emitted, then poolResolve adds each pixel's items in sample order, which is the
-// reference's `pixelColor +=` order (R/src/Core/Raytracer.cpp:84-90), so the accumulation
-// buffer gets the same bits as from renderWavefront.
-__device__ __forceinline__ void slotPixel(const RenderArgs& a, int q, int& px, int& py, bool& inside) {
-    const int tile = q >> 6, l = q & 63;
-    const int ty = tile / a.tiles_per_row_local;
-    const int k = tile - ty * a.tiles_per_row_local;
-    int base = (a.rank - ty) % a.world;
-    if (base < 0) base += a.world;
-    const int tx = base + k * a.world;
-    px = tx * kTile + (l & 7);
-    py = ty * kTile + (l >> 3);
-    inside = tx < a.tiles_x && px < a.width && py < a.height;
-}
-
-template <bool COUNT>
-__global__ void __launch_bounds__(1024) poolShade(RenderArgs a) {
-    const DevScene& sc = a.sc;
-    const PathPool& pl = a.pool;
-    __shared__ unsigned int waveCount[16];
-    __shared__ unsigned int blockBase;
-    fillCounterLut();
-    const SceneView sv = globalView(sc);
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nSlots = a.n_local_tiles * 64;
-    Stats st;
-    if (COUNT)
-        for (int j = 0; j < kNumStats; j++) st.v[j] = 0;
-
-    unsigned phase = PH_DONE;
-    uint4 m = make_uint4(0u, 0u, 0u, PH_DONE);
-    if (i < pl.n_paths) {
-        m = pl.misc[i];
-        phase = m.w;
-    }
-    Rng rng{m.x, m.y};
-    int depth = (int)m.z;
-    V3 thr{1.f, 1.f, 1.f};
-    unsigned k = 0;
-    Ray r{{0.f, 0.f, 0.f}, {0.f, 0.f, 1.f}};
-    bool emitRay = false;
-    bool needItem = phase == PH_IDLE;
-    if (phase == PH_TRACED) {
-        const float4 tk = pl.thr_k[i], hh = pl.hit[i], ro = pl.ray_o[i], rd = pl.ray_d[i];
-        thr = V3{tk.x, tk.y, tk.z};
-        k = fbits(tk.w);
-        r.o = V3{ro.x, ro.y, ro.z};
-        r.d = V3{rd.x, rd.y, rd.z};
-        const Hit h{hh.x, fbits(hh.y), hh.z, hh.w};
-        V3 terminal{0.f, 0.f, 0.f};
-        bool ended = true;
-        if (h.ref == kNoHit) {
-            if (COUNT) st.v[C_MISS]++;
-            terminal = V3{sc.bg[0], sc.bg[1], sc.bg[2]};
-        } else {
-            if (COUNT) st.v[C_HITS]++;
-            Surface sf = surfaceAt(sc, sv, r, h);
-            Ray out;
-            V3 atten, emit;
-            if (!scatter<COUNT>(sc, sv, r, sf, rng, out, atten, emit, &st)) {
-                terminal = emit;
-            } else {
-                thr = thr * atten;
-                r = out;
-                depth -= 1;
-                if (depth <= 0) {
-                    if (COUNT) st.v[C_CUTOFF]++;
-                } else {
-                    ended = false;
-                    emitRay = true;
-                }
-            }
-        }
-        if (ended) {
-            const V3 c = thr * terminal;
-            pl.colors[k] = make_float4(c.x, c.y, c.z, 0.f);
-            needItem = true;
-        }
-    }
-
-    // Work items for the slots whose path ended: one queue operation per workgroup, then (rarely:
-    // slots outside the image, max depth <= 0) one per wave until every slot has a ray or is done.
-    bool first = true;
-    for (;;) {
-        const unsigned long long mask = __ballot(needItem);
-        unsigned base;
-        if (first) {
-            if (lane == 0) waveCount[wave] = (unsigned)popc64(mask);
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                unsigned total = 0;
-                const int nw = (blockDim.x + 63) >> 6;
-                for (int w = 0; w < nw; w++) {
-                    const unsigned c = waveCount[w];
-                    waveCount[w] = total;
-                    total += c;
-                }
-                blockBase = total ? atomicAdd(pl.next_item, total) : 0u;
-            }
-            __syncthreads();
-            base = blockBase + waveCount[wave];
-            first = false;
-        } else {
-            if (mask == 0) break;
-            unsigned b = 0;
-            if (lane == __builtin_ctzll(mask)) b = atomicAdd(pl.next_item, (unsigned)popc64(mask));
-            base = __shfl(b, __builtin_ctzll(mask), 64);
-        }
-        if (needItem) {
-            const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-            k = base + (unsigned)rank;
-            if (k >= pl.n_items) {
-                needItem = false;
-                phase = PH_DONE;
-            } else {
-                const int q = (int)(k % (unsigned)nSlots);
-                const int s = a.first_sample + (int)(k / (unsigned)nSlots);
-                int px, py;
-                bool inside;
-                slotPixel(a, q, px, py, inside);
-                if (!inside) {
-                    pl.colors[k] = make_float4(0.f, 0.f, 0.f, 0.f);  // not a pixel: next item
-                } else {
-                    rng.init((uint32_t)px, (uint32_t)py, s);
-                    if (COUNT) st.v[C_SAMPLES]++;
-                    // u is drawn before v (R/src/Core/Raytracer.cpp:86-87)
-                    const float u = ((float)px + rng.next()) / (float)(a.width - 1);
-                    const float v = ((float)py + rng.next()) / (float)(a.height - 1);
-                    r = cameraRay(sc, u, v, rng);
-                    thr = V3{1.0f, 1.0f, 1.0f};
-                    depth = a.max_depth;
-                    if (depth <= 0) {
-                        if (COUNT) st.v[C_CUTOFF]++;
-                        pl.colors[k] = make_float4(0.f, 0.f, 0.f, 0.f);  // thr * 0, next item
-                    } else {
-                        needItem = false;
-                        emitRay = true;
-                        phase = PH_TRACED;
-                    }
-                }
-            }
-        }
-    }
-
-    if (i < pl.n_paths && m.w != PH_DONE) {
-        if (emitRay) {
-            pl.ray_o[i] = make_float4(r.o.x, r.o.y, r.o.z, 1.0f);
-            pl.ray_d[i] = make_float4(r.d.x, r.d.y, r.d.z, 0.0f);
-            pl.thr_k[i] = make_float4(thr.x, thr.y, thr.z, __uint_as_float(k));
-            pl.misc[i] = make_uint4(rng.key, rng.counter, (unsigned)depth, PH_TRACED);
-        } else {
-            pl.ray_o[i] = make_float4(0.f, 0.f, 0.f, 0.0f);
-            pl.misc[i] = make_uint4(0u, 0u, 0u, PH_DONE);
-        }
-    }
-    const unsigned long long em = __ballot(emitRay);
-    if (lane == 0 && em) atomicAdd(&pl.emitted[a.iter], (unsigned)popc64(em));
-    if (COUNT) {
-        for (int j = 0; j < kNumStats; j++) {
-            unsigned long long v = st.v[j];
-            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-            if (lane == 0 && v) atomicAdd(&a.counters[j < 13 ? j : 27], v);
-        }
-    }
-}
-
-// Closest hits for the pending rays of the pool.  Wave w owns the contiguous slots
-// [w * chunk, (w + 1) * chunk) and feeds its lanes from them in order, so no queue is shared
-// between waves.  Lane operations: BOX / REFBOX / PRIM as in renderWavefront, and NEXT = vouch for
-// the finished ray's hit (guard test; on failure the ray is re-traced in the reference's order
-// instead), store it, and take the wave's next slot.
-enum : int { TOP_BOX = 0, TOP_PRIM = 1, TOP_NEXT = 2, TOP_REFBOX = 3, TOP_DONE = 4 };
-
-template <bool LDS, bool COUNT>
-__global__ void __launch_bounds__(1024) poolTrace(RenderArgs a) {
-    const DevScene& sc = a.sc;
-    const PathPool& pl = a.pool;
-    SceneView sv;
-    if (LDS) {
-        sv = stageScene(sc, a.knob[2] != 0);
-    } else {
-        sv = globalView(sc);
-    }
-    const int lane = threadIdx.x & 63;
-    const int wavesPerBlock = blockDim.x >> 6;
-    const int wave = blockIdx.x * wavesPerBlock + (threadIdx.x >> 6);
-    const int nWaves = gridDim.x * wavesPerBlock;
-    const int chunk = (pl.n_paths + nWaves - 1) / nWaves;
-    int cur = wave * chunk;
-    const int end = cur + chunk < pl.n_paths ? cur + chunk : pl.n_paths;
-    const int nNodesRef = sc.n_nodes, nNodesFast = sc.n_fast_nodes;
-    const int boxKeep = a.knob[0];
-    const int nextMin = a.knob[3];
-    Stats st;
-    if (COUNT)
-        for (int j = 0; j < kNumStats; j++) st.v[j] = 0;
-    unsigned long long schedExec[7] = {0, 0, 0, 0, 0, 0, 0}, schedLanes[7] = {0, 0, 0, 0, 0, 0, 0};
-
-    int op = TOP_NEXT, slot = -1, idx = 0, p = 0, mode = 0;
-    Ray r{{0.f, 0.f, 0.f}, {0.f, 0.f, 1.f}};
-    float invx = 0.f, invy = 0.f, invz = 0.f, aa = 1.f, nox = 0.f, noy = 0.f, noz = 0.f;
-    Hit h{0.f, kNoHit, 0.f, 0.f};
-
-    for (;;) {
-        const int cBox = popc64(__ballot(op == TOP_BOX)), cPrim = popc64(__ballot(op == TOP_PRIM)),
-                  cNext = popc64(__ballot(op == TOP_NEXT)), cRef = popc64(__ballot(op == TOP_REFBOX));
-        if ((cBox | cPrim | cNext | cRef) == 0) break;
-        int chosen;
-        if (cNext >= nextMin || (cBox | cPrim | cRef) == 0) {
-            chosen = TOP_NEXT;
-        } else {
-            chosen = TOP_BOX;
-            int best = cBox;
-            if (cRef > best) { best = cRef; chosen = TOP_REFBOX; }
-            if (cPrim > best) { best = cPrim; chosen = TOP_PRIM; }
-            if (cNext > best) { best = cNext; chosen = TOP_NEXT; }
-        }
-        if (COUNT) {
-            const int slotOf[4] = {0, 1, 2, 6};
-            const int cnt[4] = {cBox, cPrim, cNext, cRef};
-            schedExec[slotOf[chosen]] += 1;
-            schedLanes[slotOf[chosen]] += cnt[chosen];
-        }
-        if (chosen == TOP_BOX) {
-            const int keep = boxKeep < cBox ? boxKeep : cBox;
-            do {
-                if (COUNT) {
-                    schedExec[5] += 1;
-                    schedLanes[5] += popc64(__ballot(op == TOP_BOX));
-                }
-                if (op == TOP_BOX) {
-                    const float4 n0 = sv.fnodes[2 * idx], n1 = sv.fnodes[2 * idx + 1];
-                    const int first = (int)fbits(n1.w);
-                    if (COUNT) st.v[C_NODE]++;
-                    const bool pass = slabPassFast(n0, n1, invx, invy, invz, nox, noy, noz, h.t);
-                    idx = pass ? idx + 1 : (int)fbits(n1.z);
-                    if (pass && first >= 0) {
-                        p = first;
-                        op = TOP_PRIM;
-                    } else if (idx >= nNodesFast) {
-                        op = TOP_NEXT;
-                    }
-                }
-            } while (popc64(__ballot(op == TOP_BOX)) >= keep && keep > 0);
-        } else if (chosen == TOP_REFBOX) {
-            const int keep = boxKeep < cRef ? boxKeep : cRef;
-            do {
-                if (COUNT) {
-                    schedExec[5] += 1;
-                    schedLanes[5] += popc64(__ballot(op == TOP_REFBOX));
-                }
-                if (op == TOP_REFBOX) {
-                    const float4 n0 = sv.nodes[2 * idx], n1 = sv.nodes[2 * idx + 1];
-                    const uint32_t w3 = fbits(n0.w);
-                    const int first = (int)fbits(n1.w);
-                    const bool nobox = (w3 & kNoBox) != 0;
-                    if (COUNT && !nobox) st.v[C_NODE]++;
-                    const bool pass = slabPass(n0, n1, r, invx, invy, invz, h.t) || nobox;
-                    idx = pass ? idx + 1 : (int)(w3 & kSkipMask);
-                    if (pass && first >= 0) {
-                        p = first;
-                        op = TOP_PRIM;
-                    } else if (idx >= nNodesRef) {
-                        op = TOP_NEXT;
-                    }
-                }
-            } while (popc64(__ballot(op == TOP_REFBOX)) >= keep && keep > 0);
-        } else if (chosen == TOP_PRIM) {
-            if (op == TOP_PRIM) {
-                const uint32_t ref = (mode ? sv.refs : sv.frefs)[p];
-                bool bad = false;
-                if (mode) {
-                    primRef<COUNT>(sv, ref, r, aa, h, &st);
-                } else {
-                    primAnyOrder<COUNT>(sv, ref, r, aa, h, bad, &st);
-                }
-                if (bad) {
-                    h.t = __builtin_inff();
-                    h.ref = kNoHit;
-                    idx = 0;
-                    op = TOP_REFBOX;
-                    mode = 1;
-                    if (COUNT) st.v[C_FALLBACK]++;
-                } else if (ref & kRefLast) {
-                    op = idx >= (mode ? nNodesRef : nNodesFast) ? TOP_NEXT : (mode ? TOP_REFBOX : TOP_BOX);
-                } else {
-                    p += 1;
-                }
-            }
-        } else {  // TOP_NEXT
-            bool take = op == TOP_NEXT;
-            if (take && slot >= 0) {
-                if (h.ref != kNoHit && mode == 0 && !guardsPass<COUNT>(sv, r, invx, invy, invz, h, &st)) {
-                    h.t = __builtin_inff();
-                    h.ref = kNoHit;
-                    idx = 0;
-                    op = TOP_REFBOX;
-                    mode = 1;
-                    if (COUNT) st.v[C_FALLBACK]++;
-                    take = false;
-                } else {
-                    pl.hit[slot] = make_float4(h.t, __uint_as_float(h.ref), h.bu, h.bv);
-                    slot = -1;
-                }
-            }
-            const unsigned long long mask = __ballot(take);
-            if (take) {
-                const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                const int j = cur + rank;
-                if (j >= end) {
-                    op = TOP_DONE;
-                } else {
-                    const float4 ro = pl.ray_o[j];
-                    if (ro.w != 0.0f) {
-                        const float4 rd = pl.ray_d[j];
-                        slot = j;
-                        r.o = V3{ro.x, ro.y, ro.z};
-                        r.d = V3{rd.x, rd.y, rd.z};
-                        invx = 1.0f / r.d.x;
-                        invy = 1.0f / r.d.y;
-                        invz = 1.0f / r.d.z;
-                        aa = dot(r.d, r.d);
-                        h.t = __builtin_inff();
-                        h.ref = kNoHit;
-                        idx = 0;
-                        nox = -(r.o.x * invx);
-                        noy = -(r.o.y * invy);
-                        noz = -(r.o.z * invz);
-                        mode = (sc.force_ref || !fastTestUsable(invx, invy, invz, nox, noy, noz)) ? 1 : 0;
-                        op = mode ? TOP_REFBOX : TOP_BOX;
-                        if (COUNT) st.v[C_RAYS]++;
-                    }  // else an idle slot: this lane asks again
-                }
-            }
-            cur += popc64(mask);
-        }
-    }
-    if (COUNT && lane == 0) {
-        for (int j = 0; j < 7; j++) {
-            atomicAdd(&a.counters[13 + 2 * j], schedExec[j]);
-            atomicAdd(&a.counters[14 + 2 * j], schedLanes[j]);
-        }
-    }
-    if (COUNT) {
-        for (int j = 0; j < kNumStats; j++) {
-            unsigned long long v = st.v[j];
-            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-            if (lane == 0 && v) atomicAdd(&a.counters[j < 13 ? j : 27], v);
-        }
-    }
-}
-
-// accum[q] += colors[s * n_slots + q] for the launch's samples in order; .w = samples so far.
-__global__ void __launch_bounds__(256) poolResolve(RenderArgs a, int n_samples) {
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    const int nSlots = a.n_local_tiles * 64;
-    if (q >= nSlots) return;
-    int px, py;
-    bool inside;
-    slotPixel(a, q, px, py, inside);
-    if (!inside) return;
-    float4 acc = a.accum[q];
-    V3 sum{acc.x, acc.y, acc.z};
-    for (int s = 0; s < n_samples; s++) {
-        const float4 c = a.pool.colors[(size_t)s * nSlots + q];
-        sum = sum + V3{c.x, c.y, c.z};
-    }
-    a.accum[q] = make_float4(sum.x, sum.y, sum.z, (float)(a.first_sample + n_samples));
-}
-
-// every slot idle, queue and per-iteration counters zero
-__global__ void poolReset(PathPool pl, int n_iter_counters) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < pl.n_paths) {
-        pl.misc[i] = make_uint4(0u, 0u, 0u, PH_IDLE);
-        pl.ray_o[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    if (i < n_iter_counters) pl.emitted[i] = 0u;
-    if (i == 0) *pl.next_item = 0u;
-}
-
 // Closest hit + hit record of arbitrary rays (test hook behind rt_trace).
 __global__ void __launch_bounds__(256) traceKernel(DevScene sc, int n, const float* rays, int* kind, int* id, float* t,
                                                    float* normal, int* front, float* uv) {
@@ -1467,44 +1076,6 @@ hipError_t launchWavefront(const RenderArgs& a, bool lds, bool count, int blocks
                           : launchWavefrontT<true, false>(a, blocks, threads, shmem, stream);
     return count ? launchWavefrontT<false, true>(a, blocks, threads, 0, stream)
                  : launchWavefrontT<false, false>(a, blocks, threads, 0, stream);
-}
-
-hipError_t launchPoolReset(const PathPool& pl, int n_iter_counters, hipStream_t stream) {
-    const int n = pl.n_paths > n_iter_counters ? pl.n_paths : n_iter_counters;
-    poolReset<<<(n + 255) / 256, 256, 0, stream>>>(pl, n_iter_counters);
-    return hipGetLastError();
-}
-
-hipError_t launchPoolShade(const RenderArgs& a, bool count, hipStream_t stream) {
-    const int blocks = (a.pool.n_paths + 1023) / 1024;
-    if (count)
-        poolShade<true><<<blocks, 1024, 0, stream>>>(a);
-    else
-        poolShade<false><<<blocks, 1024, 0, stream>>>(a);
-    return hipGetLastError();
-}
-
-template <bool LDS, bool COUNT>
-static hipError_t launchPoolTraceT(const RenderArgs& a, int blocks, int threads, size_t shmem, hipStream_t stream) {
-    if (LDS)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(poolTrace<LDS, COUNT>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    poolTrace<LDS, COUNT><<<blocks, threads, shmem, stream>>>(a);
-    return hipGetLastError();
-}
-
-hipError_t launchPoolTrace(const RenderArgs& a, bool lds, bool count, int blocks, int threads, hipStream_t stream) {
-    size_t shmem = lds ? (size_t)a.lds_bytes : 0;
-    if (lds) return count ? launchPoolTraceT<true, true>(a, blocks, threads, shmem, stream)
-                          : launchPoolTraceT<true, false>(a, blocks, threads, shmem, stream);
-    return count ? launchPoolTraceT<false, true>(a, blocks, threads, 0, stream)
-                 : launchPoolTraceT<false, false>(a, blocks, threads, 0, stream);
-}
-
-hipError_t launchPoolResolve(const RenderArgs& a, int n_samples, hipStream_t stream) {
-    const int nSlots = a.n_local_tiles * 64;
-    poolResolve<<<(nSlots + 255) / 256, 256, 0, stream>>>(a, n_samples);
-    return hipGetLastError();
 }
 
 hipError_t launchRender(const RenderArgs& a, bool lds, bool count, int blocks, int threads, hipStream_t stream) {
