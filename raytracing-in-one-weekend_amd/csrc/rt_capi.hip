@@ -156,7 +156,6 @@ int launch(rt_context* ctx, rt::RenderArgs& a, bool count) {
     a.queue = ctx->queue;
     a.knob[0] = envInt("RT_BOX_KEEP", 4);
     a.knob[1] = envInt("RT_SHADE_MIN", 32);
-    a.knob[3] = envInt("RT_POSTPONE", 1);
     int wfThreads = envInt("RT_THREADS", 512);
     if (wfThreads < 64 || wfThreads > 1024 || wfThreads % 64 != 0) wfThreads = 512;
     const int wfWaves = wfThreads / 64;

@@ -703,19 +703,12 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
     const int sEnd = a.first_sample + a.n_samples;
     const int boxKeep = a.knob[0];    // keep running BOX steps while at least this many lanes want one
     const int shadeMin = a.knob[1];   // run SHADE / NEWPATH early once this many lanes wait for it
-    const bool postpone = a.knob[3] != 0;  // keep walking with one leaf run waiting (see p, p2)
     Stats st;
     if (COUNT)
         for (int i = 0; i < kNumStats; i++) st.v[i] = 0;
 
     int op = OP_NEWPIXEL;
-    // p: next leaf reference to test (-1: none waiting); p2: start of a second leaf run found while
-    // the first was still waiting (-1: none).  In the search structure a lane that reaches a leaf
-    // does not stop: it notes the run and walks on, and only goes to PRIM with two runs in hand or
-    // at the end of the walk.  Testing the primitives later only weakens the culling by the closest
-    // hit so far (a few more box tests); the winner is chosen by smallest distance whatever the
-    // order.  The reference-order walk never postpones: there the order is the result.
-    int q = 0, px = 0, py = 0, s = 0, depth = 0, idx = 0, p = -1, p2 = -1;
+    int q = 0, px = 0, py = 0, s = 0, depth = 0, idx = 0, p = 0;
     V3 sum{0.f, 0.f, 0.f}, thr{1.f, 1.f, 1.f};
     Rng rng{0u, 0u};
     Ray r{{0.f, 0.f, 0.f}, {0.f, 0.f, 1.f}};
@@ -738,7 +731,6 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
         h.t = __builtin_inff();
         h.ref = kNoHit;
         idx = 0;
-        p = p2 = -1;
         nox = -(r.o.x * invx);
         noy = -(r.o.y * invy);
         noz = -(r.o.z * invz);
@@ -750,7 +742,6 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
         h.t = __builtin_inff();
         h.ref = kNoHit;
         idx = 0;
-        p = p2 = -1;
         op = OP_REFBOX;
         mode = 1;
         if (COUNT) st.v[C_FALLBACK]++;
@@ -813,17 +804,11 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
                     const bool pass = slabPassFast(n0, n1, invx, invy, invz, nox, noy, noz, h.t);
                     idx = pass ? idx + 1 : (int)fbits(n1.z);
                     if (pass && first >= 0) {
-                        if (p < 0 && postpone) {
-                            p = first;
-                        } else if (p < 0) {
-                            p = first;
-                            op = OP_PRIM;
-                        } else {
-                            p2 = first;
-                            op = OP_PRIM;
-                        }
+                        p = first;
+                        op = OP_PRIM;
+                    } else if (idx >= nNodesFast) {
+                        op = OP_SHADE;
                     }
-                    if (op == OP_BOX && idx >= nNodesFast) op = p >= 0 ? OP_PRIM : OP_SHADE;
                 }
             } while (popc64(__ballot(op == OP_BOX)) >= keep && keep > 0);
         } else if (chosen == OP_REFBOX) {
@@ -862,9 +847,7 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
                 if (bad) {
                     retraceInReferenceOrder();
                 } else if (ref & kRefLast) {
-                    p = p2;
-                    p2 = -1;
-                    if (p < 0) op = idx >= (mode ? nNodesRef : nNodesFast) ? OP_SHADE : (mode ? OP_REFBOX : OP_BOX);
+                    op = idx >= (mode ? nNodesRef : nNodesFast) ? OP_SHADE : (mode ? OP_REFBOX : OP_BOX);
                 } else {
                     p += 1;
                 }
