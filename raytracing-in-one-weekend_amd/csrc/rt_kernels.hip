@@ -682,7 +682,13 @@ __global__ void __launch_bounds__(256) renderKernel(RenderArgs a) {
 // OP_BOX walks the search structure, OP_REFBOX the reference-order array (lanes with mode == 1).
 enum : int { OP_BOX = 0, OP_PRIM = 1, OP_SHADE = 2, OP_NEWPATH = 3, OP_NEWPIXEL = 4, OP_REFBOX = 5, OP_DONE = 6 };
 
-__device__ __forceinline__ int popc64(unsigned long long m) { return __builtin_popcountll(m); }
+// Lanes set in a ballot mask, as a 32-bit scalar.  (__builtin_popcountll keeps the count 64 bits
+// wide, and every comparison between counts then goes through 64-bit vector compares.)
+__device__ __forceinline__ int popc64(unsigned long long m) {
+    int c;
+    asm("s_bcnt1_i32_b64 %0, %1" : "=s"(c) : "s"(m) : "scc");
+    return c;
+}
 
 #ifndef WF_BOUNDS
 #define WF_BOUNDS 1024
