@@ -54,6 +54,8 @@ struct rt_context {
     int force_ref = 0;
     bool huge_coords = false;
     unsigned long long sched_stats[14] = {0};  // from the last rt_count(): {executions, lanes} per operation
+    float4* colors = nullptr;  // per-sample radiance of the split mode (grown on demand)
+    size_t colors_cap = 0;     // in float4
 };
 
 namespace {
@@ -152,7 +154,6 @@ int launch(rt_context* ctx, rt::RenderArgs& a, bool count) {
         HIP_TRY(rt::launchRender(a, ctx->use_lds, count, blocks, threads, ctx->stream));
         return RT_OK;
     }
-    HIP_TRY(hipMemsetAsync(ctx->queue, 0, 256, ctx->stream));
     a.queue = ctx->queue;
     a.knob[0] = envInt("RT_BOX_KEEP", 4);
     a.knob[1] = envInt("RT_SHADE_MIN", 32);
@@ -161,11 +162,57 @@ int launch(rt_context* ctx, rt::RenderArgs& a, bool count) {
     const int wfWaves = wfThreads / 64;
     // two 512-thread workgroups per CU = 4 waves per SIMD: measured best (a scene staged in LDS
     // leaves room for two workgroups; more waves per SIMD ran slower, fewer too)
-    blocks = ctx->n_cus * envInt("RT_BLOCKS_PER_CU", 2);
-    const int needed = (a.n_local_tiles + wfWaves - 1) / wfWaves;
-    if (blocks > needed) blocks = needed;
-    if (blocks < 1) blocks = 1;
-    HIP_TRY(rt::launchWavefront(a, ctx->use_lds, count, blocks, wfThreads, ctx->stream));
+    const int maxBlocks = ctx->n_cus * envInt("RT_BLOCKS_PER_CU", 2);
+
+    // Work units.  A lane sums one pixel's samples in order, so with whole pixels as units the
+    // launch lasts as long as its most expensive pixels: lanes that finish early find the queue
+    // dry (1.3x at 1080p / 64 spp on one GPU, 5.7x for one of eight ranks at 512 spp).  So the
+    // unit is a run of `unit_samples` samples of a pixel, per-sample radiance goes through a
+    // colour buffer and a second kernel adds it in sample order (same bits).  RT_SPLIT=0 turns
+    // this off (whole pixels, sums in registers).
+    const long long nSlots = (long long)a.n_local_tiles * 64;
+    const int splitEnv = envInt("RT_SPLIT", -1);
+    const bool split = splitEnv != 0;
+    if (!split) {
+        int blocks = maxBlocks;
+        const int needed = (a.n_local_tiles + wfWaves - 1) / wfWaves;
+        if (blocks > needed) blocks = needed;
+        if (blocks < 1) blocks = 1;
+        HIP_TRY(hipMemsetAsync(ctx->queue, 0, 256, ctx->stream));
+        HIP_TRY(rt::launchWavefront(a, ctx->use_lds, count, blocks, wfThreads, ctx->stream));
+        return RT_OK;
+    }
+    const size_t budget = (size_t)std::max(16, envInt("RT_COLORS_MB", 4096)) << 20;
+    const int maxSamples = (int)std::max<size_t>(1, std::min<size_t>((size_t)a.n_samples, budget / ((size_t)nSlots * 16)));
+    const int first = a.first_sample, total = a.n_samples;
+    for (int s0 = 0; s0 < total; s0 += maxSamples) {
+        const int ns = std::min(maxSamples, total - s0);
+        const size_t need = (size_t)nSlots * (size_t)ns;
+        if (need > ctx->colors_cap) {
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            if (ctx->colors) (void)hipFree(ctx->colors);
+            ctx->colors = nullptr;
+            ctx->colors_cap = 0;
+            HIP_TRY(hipMalloc((void**)&ctx->colors, need * sizeof(float4)));
+            ctx->colors_cap = need;
+        }
+        a.first_sample = first + s0;
+        a.n_samples = ns;
+        a.colors = ctx->colors;
+        // one sample per unit measured fastest (39 ms; 2: 43, 4: 45, 8: 46, 16: 49, 32: 55, 64 = whole pixels: 64)
+        int unit = envInt("RT_UNIT_SAMPLES", 1);
+        if (unit < 1) unit = 1;
+        if (unit > ns) unit = ns;
+        a.unit_samples = unit;
+        const long long chunks = (ns + unit - 1) / unit;
+        if (nSlots * chunks >= (1ll << 31)) return fail(RT_ERR_LIMIT, "too many work units in one pass");
+        int blocks = maxBlocks;
+        const long long needed = (a.n_local_tiles * chunks + wfWaves - 1) / wfWaves;
+        if (blocks > needed) blocks = (int)needed;
+        if (blocks < 1) blocks = 1;
+        HIP_TRY(hipMemsetAsync(ctx->queue, 0, 256, ctx->stream));
+        HIP_TRY(rt::launchWavefront(a, ctx->use_lds, count, blocks, wfThreads, ctx->stream));
+    }
     return RT_OK;
 }
 
@@ -362,6 +409,7 @@ void rt_destroy(rt_context* ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     freeScene(ctx);
     freeTarget(ctx);
+    if (ctx->colors) (void)hipFree(ctx->colors);
     if (ctx->queue) (void)hipFree(ctx->queue);
     if (ctx->counters) (void)hipFree(ctx->counters);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);

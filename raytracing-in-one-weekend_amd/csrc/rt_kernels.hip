@@ -693,7 +693,7 @@ __device__ __forceinline__ int popc64(unsigned long long m) {
 #ifndef WF_BOUNDS
 #define WF_BOUNDS 1024
 #endif
-template <bool LDS, bool COUNT>
+template <bool LDS, bool COUNT, bool SPLIT>
 __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
     const DevScene& sc = a.sc;
     fillCounterLut();
@@ -707,6 +707,10 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
     const int nNodesRef = sc.n_nodes, nNodesFast = sc.n_fast_nodes;
     const int nSlots = a.n_local_tiles * 64;
     const int sEnd = a.first_sample + a.n_samples;
+    // work units in the queue: pixels, or (SPLIT) pixels x sample chunks, chunk-major
+    const int nChunks = SPLIT ? (a.n_samples + a.unit_samples - 1) / a.unit_samples : 1;
+    const unsigned int nUnits = (unsigned int)nSlots * (unsigned int)nChunks;
+    int sStop = sEnd;  // first sample this lane's unit does not cover
     const int boxKeep = a.knob[0];    // keep running BOX steps while at least this many lanes want one
     const int shadeMin = a.knob[1];   // run SHADE / NEWPATH early once this many lanes wait for it
     Stats st;
@@ -754,7 +758,11 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
     };
     auto endPath = [&](V3 terminal) {
         V3 c = thr * terminal;
-        sum = sum + c;
+        if (SPLIT) {
+            a.colors[(size_t)(s - a.first_sample) * nSlots + q] = make_float4(c.x, c.y, c.z, 0.f);
+        } else {
+            sum = sum + c;
+        }
         s += 1;
         op = OP_NEWPATH;
     };
@@ -887,8 +895,8 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
             }
         } else if (chosen == OP_NEWPATH) {
             if (op == OP_NEWPATH) {
-                if (s >= sEnd) {
-                    a.accum[q] = make_float4(sum.x, sum.y, sum.z, (float)sEnd);
+                if (s >= sStop) {
+                    if (!SPLIT) a.accum[q] = make_float4(sum.x, sum.y, sum.z, (float)sEnd);
                     op = OP_NEWPIXEL;
                 } else {
                     rng.init((uint32_t)px, (uint32_t)py, s);
@@ -907,7 +915,7 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
                     }
                 }
             }
-        } else {  // OP_NEWPIXEL: hand the waiting lanes the next pixel slots, in lane order
+        } else {  // OP_NEWPIXEL: hand the waiting lanes the next work units, in lane order
             const bool want = op == OP_NEWPIXEL;
             const unsigned long long m = __ballot(want);
             const int need = popc64(m);
@@ -915,11 +923,11 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
                 unsigned int base = 0;
                 if (lane == 0) base = atomicAdd(a.queue, 64u);
                 base = __builtin_amdgcn_readfirstlane(base);
-                if (base >= (unsigned int)nSlots) {
+                if (base >= nUnits) {
                     poolNext = poolEnd = -1;  // the queue is dry
                 } else {
                     poolNext = (int)base;
-                    poolEnd = (int)base + 64 < nSlots ? (int)base + 64 : nSlots;
+                    poolEnd = base + 64u < nUnits ? (int)base + 64 : (int)nUnits;
                 }
             }
             const int avail = poolEnd < 0 ? 0 : poolEnd - poolNext;
@@ -929,7 +937,9 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
                 if (poolEnd < 0) {
                     op = OP_DONE;
                 } else if (rankInMask < avail) {
-                    q = poolNext + rankInMask;
+                    const int unit = poolNext + rankInMask;
+                    const int chunkIdx = SPLIT ? unit / nSlots : 0;
+                    q = unit - chunkIdx * nSlots;
                     const int tile = q >> 6, l = q & 63;
                     const int ty = tile / a.tiles_per_row_local;
                     const int k = tile - ty * a.tiles_per_row_local;
@@ -939,9 +949,14 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
                     px = tx * kTile + (l & 7);
                     py = ty * kTile + (l >> 3);
                     if (tx < a.tiles_x && px < a.width && py < a.height) {
-                        const float4 acc = a.accum[q];
-                        sum = V3{acc.x, acc.y, acc.z};
-                        s = a.first_sample;
+                        if (SPLIT) {
+                            s = a.first_sample + chunkIdx * a.unit_samples;
+                            sStop = s + a.unit_samples < sEnd ? s + a.unit_samples : sEnd;
+                        } else {
+                            const float4 acc = a.accum[q];
+                            sum = V3{acc.x, acc.y, acc.z};
+                            s = a.first_sample;
+                        }
                         op = OP_NEWPATH;
                     }  // else a padding slot outside the image: this lane asks again
                 }      // else the pool ran out before this lane's turn: it asks again
@@ -963,6 +978,29 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
             if (lane == 0 && v) atomicAdd(&a.counters[i < 13 ? i : 27], v);
         }
     }
+}
+
+// Split mode's second step: accum[q] += colors[s][q] for the launch's samples in order (the
+// reference's `pixelColor +=` order, R/src/Core/Raytracer.cpp:84-90); .w = samples so far.
+__global__ void __launch_bounds__(256) accumulateColors(RenderArgs a) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nSlots = a.n_local_tiles * 64;
+    if (q >= nSlots) return;
+    const int tile = q >> 6, l = q & 63;
+    const int ty = tile / a.tiles_per_row_local;
+    const int k = tile - ty * a.tiles_per_row_local;
+    int base = (a.rank - ty) % a.world;
+    if (base < 0) base += a.world;
+    const int tx = base + k * a.world;
+    const int px = tx * kTile + (l & 7), py = ty * kTile + (l >> 3);
+    if (!(tx < a.tiles_x && px < a.width && py < a.height)) return;
+    const float4 acc = a.accum[q];
+    V3 sum{acc.x, acc.y, acc.z};
+    for (int s = 0; s < a.n_samples; s++) {
+        const float4 c = a.colors[(size_t)s * nSlots + q];
+        sum = sum + V3{c.x, c.y, c.z};
+    }
+    a.accum[q] = make_float4(sum.x, sum.y, sum.z, (float)(a.first_sample + a.n_samples));
 }
 
 // Closest hit + hit record of arbitrary rays (test hook behind rt_trace).
@@ -1067,21 +1105,31 @@ __global__ void __launch_bounds__(256) resolveKernel(const float4* payloads, siz
 }
 
 // ------------------------------------------------------------------ launch wrappers
-template <bool LDS, bool COUNT>
+template <bool LDS, bool COUNT, bool SPLIT>
 static hipError_t launchWavefrontT(const RenderArgs& a, int blocks, int threads, size_t shmem, hipStream_t stream) {
     if (LDS)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(renderWavefront<LDS, COUNT>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(renderWavefront<LDS, COUNT, SPLIT>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    renderWavefront<LDS, COUNT><<<blocks, threads, shmem, stream>>>(a);
+    renderWavefront<LDS, COUNT, SPLIT><<<blocks, threads, shmem, stream>>>(a);
+    return hipGetLastError();
+}
+
+template <bool LDS, bool COUNT>
+static hipError_t launchWavefrontS(const RenderArgs& a, int blocks, int threads, size_t shmem, hipStream_t stream) {
+    if (!a.colors) return launchWavefrontT<LDS, COUNT, false>(a, blocks, threads, shmem, stream);
+    hipError_t e = launchWavefrontT<LDS, COUNT, true>(a, blocks, threads, shmem, stream);
+    if (e != hipSuccess) return e;
+    const int nSlots = a.n_local_tiles * 64;
+    accumulateColors<<<(nSlots + 255) / 256, 256, 0, stream>>>(a);
     return hipGetLastError();
 }
 
 hipError_t launchWavefront(const RenderArgs& a, bool lds, bool count, int blocks, int threads, hipStream_t stream) {
     size_t shmem = lds ? (size_t)a.lds_bytes : 0;
-    if (lds) return count ? launchWavefrontT<true, true>(a, blocks, threads, shmem, stream)
-                          : launchWavefrontT<true, false>(a, blocks, threads, shmem, stream);
-    return count ? launchWavefrontT<false, true>(a, blocks, threads, 0, stream)
-                 : launchWavefrontT<false, false>(a, blocks, threads, 0, stream);
+    if (lds) return count ? launchWavefrontS<true, true>(a, blocks, threads, shmem, stream)
+                          : launchWavefrontS<true, false>(a, blocks, threads, shmem, stream);
+    return count ? launchWavefrontS<false, true>(a, blocks, threads, 0, stream)
+                 : launchWavefrontS<false, false>(a, blocks, threads, 0, stream);
 }
 
 hipError_t launchRender(const RenderArgs& a, bool lds, bool count, int blocks, int threads, hipStream_t stream) {
