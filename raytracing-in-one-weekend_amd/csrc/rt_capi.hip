@@ -155,7 +155,7 @@ int launch(rt_context* ctx, rt::RenderArgs& a, bool count) {
         return RT_OK;
     }
     a.queue = ctx->queue;
-    a.knob[0] = envInt("RT_BOX_KEEP", 4);
+    a.knob[0] = envInt("RT_BOX_KEEP", 8);
     a.knob[1] = envInt("RT_SHADE_MIN", 32);
     int wfThreads = envInt("RT_THREADS", 512);
     if (wfThreads < 64 || wfThreads > 1024 || wfThreads % 64 != 0) wfThreads = 512;
@@ -164,29 +164,17 @@ int launch(rt_context* ctx, rt::RenderArgs& a, bool count) {
     // leaves room for two workgroups; more waves per SIMD ran slower, fewer too)
     const int maxBlocks = ctx->n_cus * envInt("RT_BLOCKS_PER_CU", 2);
 
-    // Work units.  A lane sums one pixel's samples in order, so with whole pixels as units the
-    // launch lasts as long as its most expensive pixels: lanes that finish early find the queue
-    // dry (1.3x at 1080p / 64 spp on one GPU, 5.7x for one of eight ranks at 512 spp).  So the
-    // unit is a run of `unit_samples` samples of a pixel, per-sample radiance goes through a
-    // colour buffer and a second kernel adds it in sample order (same bits).  RT_SPLIT=0 turns
-    // this off (whole pixels, sums in registers).
+    // The kernel writes one radiance per pixel sample into the colour buffer and a second kernel
+    // adds them per pixel in sample order; launches are cut so that the buffer stays within
+    // RT_COLORS_MB (default 4096) and the queue index within 32 bits.
     const long long nSlots = (long long)a.n_local_tiles * 64;
-    const int splitEnv = envInt("RT_SPLIT", -1);
-    const bool split = splitEnv != 0;
-    if (!split) {
-        int blocks = maxBlocks;
-        const int needed = (a.n_local_tiles + wfWaves - 1) / wfWaves;
-        if (blocks > needed) blocks = needed;
-        if (blocks < 1) blocks = 1;
-        HIP_TRY(hipMemsetAsync(ctx->queue, 0, 256, ctx->stream));
-        HIP_TRY(rt::launchWavefront(a, ctx->use_lds, count, blocks, wfThreads, ctx->stream));
-        return RT_OK;
-    }
     const size_t budget = (size_t)std::max(16, envInt("RT_COLORS_MB", 4096)) << 20;
-    const int maxSamples = (int)std::max<size_t>(1, std::min<size_t>((size_t)a.n_samples, budget / ((size_t)nSlots * 16)));
+    size_t maxSamples = std::max<size_t>(1, budget / ((size_t)nSlots * 16));
+    maxSamples = std::min<size_t>(maxSamples, (size_t)((1ll << 31) / nSlots));
+    maxSamples = std::max<size_t>(1, std::min<size_t>(maxSamples, (size_t)a.n_samples));
     const int first = a.first_sample, total = a.n_samples;
-    for (int s0 = 0; s0 < total; s0 += maxSamples) {
-        const int ns = std::min(maxSamples, total - s0);
+    for (int s0 = 0; s0 < total; s0 += (int)maxSamples) {
+        const int ns = std::min((int)maxSamples, total - s0);
         const size_t need = (size_t)nSlots * (size_t)ns;
         if (need > ctx->colors_cap) {
             HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -199,15 +187,8 @@ int launch(rt_context* ctx, rt::RenderArgs& a, bool count) {
         a.first_sample = first + s0;
         a.n_samples = ns;
         a.colors = ctx->colors;
-        // one sample per unit measured fastest (39 ms; 2: 43, 4: 45, 8: 46, 16: 49, 32: 55, 64 = whole pixels: 64)
-        int unit = envInt("RT_UNIT_SAMPLES", 1);
-        if (unit < 1) unit = 1;
-        if (unit > ns) unit = ns;
-        a.unit_samples = unit;
-        const long long chunks = (ns + unit - 1) / unit;
-        if (nSlots * chunks >= (1ll << 31)) return fail(RT_ERR_LIMIT, "too many work units in one pass");
         int blocks = maxBlocks;
-        const long long needed = (a.n_local_tiles * chunks + wfWaves - 1) / wfWaves;
+        const long long needed = ((long long)a.n_local_tiles * ns + wfWaves - 1) / wfWaves;
         if (blocks > needed) blocks = (int)needed;
         if (blocks < 1) blocks = 1;
         HIP_TRY(hipMemsetAsync(ctx->queue, 0, 256, ctx->stream));

@@ -47,12 +47,9 @@ struct RenderArgs {
     int first_sample, n_samples, max_depth;
     int lds_bytes;
     int knob[4];  // scheduling thresholds of the wavefront loop (never affect results)
-    // Split mode (colors != null): the unit of work a lane takes from the queue is `unit_samples`
-    // consecutive samples of one pixel instead of the whole pixel, each sample's radiance goes to
-    // colors[(sample - first_sample) * n_slots + pixel slot], and accumulateColors() adds them to
-    // the accumulation buffer in sample order afterwards (same bits as summing in a register).
+    // per-sample radiance of the launch: colors[(sample - first_sample) * n_slots + pixel slot],
+    // added to the accumulation buffer in sample order by accumulateColors()
     float4* colors;
-    int unit_samples;
 };
 
 constexpr int kTile = 8;  // one wave64 = one 8x8 pixel tile

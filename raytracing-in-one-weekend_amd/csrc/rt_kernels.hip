@@ -670,17 +670,22 @@ __global__ void __launch_bounds__(256) renderKernel(RenderArgs a) {
 // ---------------------------------------------------------------------------------------
 // Persistent wavefront loop.
 //
-// Every lane is a small state machine that walks one pixel at a time through its samples:
-//   NEWPIXEL -> NEWPATH -> (BOX | PRIM)* -> SHADE -> (BOX ... | NEWPATH) ... -> NEWPIXEL
-// and carries the name of the operation it needs next.  Each trip round the loop the wave
-// ballots the lanes per operation, picks one operation, and runs it for exactly the lanes
-// that want it; the others wait with their state in registers.  Lanes that finish a path
-// regenerate a camera ray for their next sample, lanes that finish a pixel pull the next
-// pixel from the launch-wide queue, so no lane idles until the queue is dry.  Which lane
-// runs when never changes what a lane computes: a pixel's samples are still summed by one
-// lane in sample order, and the random stream is keyed by (x, y, sample, counter).
+// The unit of work is one pixel sample (one camera path).  Units are numbered sample-major,
+// unit = sample * n_slots + pixel slot, and handed out in order from a launch-wide queue, 64 at a
+// time per wave: one 8x8 tile of one sample.  Every lane is a small state machine
+//   NEWPATH -> (BOX | PRIM)* -> SHADE -> (BOX ... | NEWPATH) ...
+// that carries the name of the operation it needs next.  Each trip round the loop the wave
+// ballots the lanes per operation, picks one operation, and runs it for exactly the lanes that
+// want it; the others wait with their state in registers.  A lane whose path ends writes the
+// path's radiance to colors[unit] and takes the next unit, so no lane idles until the queue is
+// dry, and the queue is dry only when less than one path per lane is left.  (With whole pixels as
+// units, lanes holding expensive pixels ran on long after the queue was dry: 67 ms instead of
+// 39.5 ms per 1080p 64-spp frame, and 290 ms for one of eight ranks at 512 spp.)
+// accumulateColors() then adds every pixel's radiances in sample order, which is the reference's
+// `pixelColor +=` order (R/src/Core/Raytracer.cpp:84-90).  Which lane runs when never changes
+// what a path computes: the random stream is keyed by (x, y, sample, counter).
 // OP_BOX walks the search structure, OP_REFBOX the reference-order array (lanes with mode == 1).
-enum : int { OP_BOX = 0, OP_PRIM = 1, OP_SHADE = 2, OP_NEWPATH = 3, OP_NEWPIXEL = 4, OP_REFBOX = 5, OP_DONE = 6 };
+enum : int { OP_BOX = 0, OP_PRIM = 1, OP_SHADE = 2, OP_NEWPATH = 3, OP_REFBOX = 4, OP_DONE = 5 };
 
 // Lanes set in a ballot mask, as a 32-bit scalar.  (__builtin_popcountll keeps the count 64 bits
 // wide, and every comparison between counts then goes through 64-bit vector compares.)
@@ -693,7 +698,7 @@ __device__ __forceinline__ int popc64(unsigned long long m) {
 #ifndef WF_BOUNDS
 #define WF_BOUNDS 1024
 #endif
-template <bool LDS, bool COUNT, bool SPLIT>
+template <bool LDS, bool COUNT>
 __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
     const DevScene& sc = a.sc;
     fillCounterLut();
@@ -705,21 +710,18 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
     }
     const int lane = threadIdx.x & 63;
     const int nNodesRef = sc.n_nodes, nNodesFast = sc.n_fast_nodes;
-    const int nSlots = a.n_local_tiles * 64;
-    const int sEnd = a.first_sample + a.n_samples;
-    // work units in the queue: pixels, or (SPLIT) pixels x sample chunks, chunk-major
-    const int nChunks = SPLIT ? (a.n_samples + a.unit_samples - 1) / a.unit_samples : 1;
-    const unsigned int nUnits = (unsigned int)nSlots * (unsigned int)nChunks;
-    int sStop = sEnd;  // first sample this lane's unit does not cover
+    const int nTiles = a.n_local_tiles;
+    const unsigned int nChunks = (unsigned int)nTiles * (unsigned int)a.n_samples;  // 64 units each
     const int boxKeep = a.knob[0];    // keep running BOX steps while at least this many lanes want one
     const int shadeMin = a.knob[1];   // run SHADE / NEWPATH early once this many lanes wait for it
     Stats st;
     if (COUNT)
         for (int i = 0; i < kNumStats; i++) st.v[i] = 0;
 
-    int op = OP_NEWPIXEL;
-    int q = 0, px = 0, py = 0, s = 0, depth = 0, idx = 0, p = 0;
-    V3 sum{0.f, 0.f, 0.f}, thr{1.f, 1.f, 1.f};
+    int op = OP_NEWPATH;
+    int depth = 0, idx = 0, p = 0;
+    unsigned int unit = 0;
+    V3 thr{1.f, 1.f, 1.f};
     Rng rng{0u, 0u};
     Ray r{{0.f, 0.f, 0.f}, {0.f, 0.f, 1.f}};
     float invx = 0.f, invy = 0.f, invz = 0.f, aa = 1.f;
@@ -729,8 +731,11 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
     // setting, zero direction component, or a re-trace after a failed guard test / NaN distance)
     int mode = 0;
 
-    // wave-local pool of pixel slots pulled from the launch-wide queue 64 at a time
-    int poolNext = 0, poolEnd = 0;
+    // The wave's current chunk of the queue: 64 units = the 64 pixels of one tile for one sample.
+    // chunkNext counts the lanes' worth already handed out (64 = used up), chunk < 0 = queue dry.
+    int chunk = 0, chunkNext = 64;
+    int chunkSample = 0, chunkX0 = 0, chunkY0 = 0;
+    bool chunkInside = false;
     unsigned long long schedExec[7] = {0, 0, 0, 0, 0, 0, 0}, schedLanes[7] = {0, 0, 0, 0, 0, 0, 0};
 
     auto startRay = [&]() {
@@ -757,34 +762,21 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
         if (COUNT) st.v[C_FALLBACK]++;
     };
     auto endPath = [&](V3 terminal) {
-        V3 c = thr * terminal;
-        if (SPLIT) {
-            a.colors[(size_t)(s - a.first_sample) * nSlots + q] = make_float4(c.x, c.y, c.z, 0.f);
-        } else {
-            sum = sum + c;
-        }
-        s += 1;
+        const V3 c = thr * terminal;
+        a.colors[unit] = make_float4(c.x, c.y, c.z, 0.f);
         op = OP_NEWPATH;
     };
 
     for (;;) {
-        const unsigned long long mBox = __ballot(op == OP_BOX);
-        const unsigned long long mPrim = __ballot(op == OP_PRIM);
-        const unsigned long long mShade = __ballot(op == OP_SHADE);
-        const unsigned long long mPath = __ballot(op == OP_NEWPATH);
-        const unsigned long long mPixel = __ballot(op == OP_NEWPIXEL);
-        const unsigned long long mRef = __ballot(op == OP_REFBOX);
-        const int cBox = popc64(mBox), cPrim = popc64(mPrim), cShade = popc64(mShade), cPath = popc64(mPath),
-                  cPixel = popc64(mPixel), cRef = popc64(mRef);
-        if ((cBox | cPrim | cShade | cPath | cPixel | cRef) == 0) break;
+        const int cBox = popc64(__ballot(op == OP_BOX)), cPrim = popc64(__ballot(op == OP_PRIM)),
+                  cShade = popc64(__ballot(op == OP_SHADE)), cPath = popc64(__ballot(op == OP_NEWPATH)),
+                  cRef = popc64(__ballot(op == OP_REFBOX));
+        if ((cBox | cPrim | cShade | cPath | cRef) == 0) break;
 
-        // Pick the operation to run: the cheap bookkeeping ones first, then whichever of the
-        // traversal / shading operations has the most lanes waiting (shading is the costly one,
-        // so it also goes as soon as `shadeMin` lanes have piled up).
+        // Pick the operation to run: whichever has the most lanes waiting; shading and path
+        // set-up are the costly ones, so they also go as soon as `shadeMin` lanes have piled up.
         int chosen;
-        if (cPixel > 0 && (cPixel >= 16 || (cBox | cPrim | cShade | cPath | cRef) == 0)) {
-            chosen = OP_NEWPIXEL;
-        } else if (cShade >= shadeMin || cPath >= shadeMin) {
+        if (cShade >= shadeMin || cPath >= shadeMin) {
             chosen = cShade >= cPath ? OP_SHADE : OP_NEWPATH;
         } else {
             chosen = OP_BOX;
@@ -793,11 +785,10 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
             if (cPrim > best) { best = cPrim; chosen = OP_PRIM; }
             if (cShade > best) { best = cShade; chosen = OP_SHADE; }
             if (cPath > best) { best = cPath; chosen = OP_NEWPATH; }
-            if (best == 0) chosen = OP_NEWPIXEL;
         }
 
         if (COUNT) {  // scheduling statistics: executions and waiting lanes per operation
-            const int cnt[6] = {cBox, cPrim, cShade, cPath, cPixel, cRef};
+            const int cnt[5] = {cBox, cPrim, cShade, cPath, cRef};
             const int slot = chosen == OP_REFBOX ? 6 : chosen;
             schedExec[slot] += 1;
             schedLanes[slot] += cnt[chosen];
@@ -893,75 +884,60 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
                     }
                 }
             }
-        } else if (chosen == OP_NEWPATH) {
-            if (op == OP_NEWPATH) {
-                if (s >= sStop) {
-                    if (!SPLIT) a.accum[q] = make_float4(sum.x, sum.y, sum.z, (float)sEnd);
-                    op = OP_NEWPIXEL;
-                } else {
-                    rng.init((uint32_t)px, (uint32_t)py, s);
-                    if (COUNT) st.v[C_SAMPLES]++;
-                    // u is drawn before v (R/src/Core/Raytracer.cpp:86-87)
-                    float u = ((float)px + rng.next()) / (float)(a.width - 1);
-                    float v = ((float)py + rng.next()) / (float)(a.height - 1);
-                    r = cameraRay(sc, u, v, rng);
-                    thr = V3{1.0f, 1.0f, 1.0f};
-                    depth = a.max_depth;
-                    if (depth <= 0) {
-                        if (COUNT) st.v[C_CUTOFF]++;
-                        endPath(V3{0.0f, 0.0f, 0.0f});
-                    } else {
-                        startRay();
-                    }
-                }
-            }
-        } else {  // OP_NEWPIXEL: hand the waiting lanes the next work units, in lane order
-            const bool want = op == OP_NEWPIXEL;
+        } else {  // OP_NEWPATH: the next unit for every waiting lane, in lane order, and its camera ray
+            const bool want = op == OP_NEWPATH;
             const unsigned long long m = __ballot(want);
-            const int need = popc64(m);
-            if (poolEnd >= 0 && poolNext >= poolEnd) {  // pool used up: pull the next 64 slots
-                unsigned int base = 0;
-                if (lane == 0) base = atomicAdd(a.queue, 64u);
-                base = __builtin_amdgcn_readfirstlane(base);
-                if (base >= nUnits) {
-                    poolNext = poolEnd = -1;  // the queue is dry
+            if (chunk >= 0 && chunkNext >= 64) {  // chunk used up: take the next one from the queue
+                unsigned int c = 0;
+                if (lane == 0) c = atomicAdd(a.queue, 1u);
+                c = __builtin_amdgcn_readfirstlane(c);
+                if (c >= nChunks) {
+                    chunk = -1;  // the queue is dry
                 } else {
-                    poolNext = (int)base;
-                    poolEnd = base + 64u < nUnits ? (int)base + 64 : (int)nUnits;
-                }
-            }
-            const int avail = poolEnd < 0 ? 0 : poolEnd - poolNext;
-            if (want) {
-                const int rankInMask =
-                    __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                if (poolEnd < 0) {
-                    op = OP_DONE;
-                } else if (rankInMask < avail) {
-                    const int unit = poolNext + rankInMask;
-                    const int chunkIdx = SPLIT ? unit / nSlots : 0;
-                    q = unit - chunkIdx * nSlots;
-                    const int tile = q >> 6, l = q & 63;
+                    chunk = (int)c;
+                    chunkNext = 0;
+                    // chunk -> (sample, tile) -> the tile's corner pixel, all wave-uniform
+                    const int sIdx = (int)(c / (unsigned int)nTiles);
+                    const int tile = (int)(c - (unsigned int)sIdx * (unsigned int)nTiles);
                     const int ty = tile / a.tiles_per_row_local;
                     const int k = tile - ty * a.tiles_per_row_local;
                     int base = (a.rank - ty) % a.world;
                     if (base < 0) base += a.world;
                     const int tx = base + k * a.world;
-                    px = tx * kTile + (l & 7);
-                    py = ty * kTile + (l >> 3);
-                    if (tx < a.tiles_x && px < a.width && py < a.height) {
-                        if (SPLIT) {
-                            s = a.first_sample + chunkIdx * a.unit_samples;
-                            sStop = s + a.unit_samples < sEnd ? s + a.unit_samples : sEnd;
-                        } else {
-                            const float4 acc = a.accum[q];
-                            sum = V3{acc.x, acc.y, acc.z};
-                            s = a.first_sample;
-                        }
-                        op = OP_NEWPATH;
-                    }  // else a padding slot outside the image: this lane asks again
-                }      // else the pool ran out before this lane's turn: it asks again
+                    chunkSample = a.first_sample + sIdx;
+                    chunkX0 = tx * kTile;
+                    chunkY0 = ty * kTile;
+                    chunkInside = tx < a.tiles_x;
+                }
             }
-            poolNext += need < avail ? need : avail;
+            if (want) {
+                const int rankInMask =
+                    __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                const int l = chunkNext + rankInMask;  // pixel inside the tile
+                if (chunk < 0) {
+                    op = OP_DONE;
+                } else if (l < 64) {
+                    const int px = chunkX0 + (l & 7), py = chunkY0 + (l >> 3);
+                    unit = (unsigned int)chunk * 64u + (unsigned int)l;
+                    if (chunkInside && px < a.width && py < a.height) {
+                        rng.init((uint32_t)px, (uint32_t)py, chunkSample);
+                        if (COUNT) st.v[C_SAMPLES]++;
+                        // u is drawn before v (R/src/Core/Raytracer.cpp:86-87)
+                        float u = ((float)px + rng.next()) / (float)(a.width - 1);
+                        float v = ((float)py + rng.next()) / (float)(a.height - 1);
+                        r = cameraRay(sc, u, v, rng);
+                        thr = V3{1.0f, 1.0f, 1.0f};
+                        depth = a.max_depth;
+                        if (depth <= 0) {
+                            if (COUNT) st.v[C_CUTOFF]++;
+                            endPath(V3{0.0f, 0.0f, 0.0f});
+                        } else {
+                            startRay();
+                        }
+                    }  // else not a pixel of the image: this lane asks again
+                }      // else the chunk ran out before this lane's turn: it asks again
+            }
+            chunkNext += popc64(m);
         }
     }
     if (COUNT && lane == 0) {
@@ -980,8 +956,8 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
     }
 }
 
-// Split mode's second step: accum[q] += colors[s][q] for the launch's samples in order (the
-// reference's `pixelColor +=` order, R/src/Core/Raytracer.cpp:84-90); .w = samples so far.
+// Second step of a render launch: accum[q] += colors[s * n_slots + q] for the launch's samples in
+// order (the reference's `pixelColor +=` order, R/src/Core/Raytracer.cpp:84-90); .w = samples so far.
 __global__ void __launch_bounds__(256) accumulateColors(RenderArgs a) {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     const int nSlots = a.n_local_tiles * 64;
@@ -1105,19 +1081,13 @@ __global__ void __launch_bounds__(256) resolveKernel(const float4* payloads, siz
 }
 
 // ------------------------------------------------------------------ launch wrappers
-template <bool LDS, bool COUNT, bool SPLIT>
+template <bool LDS, bool COUNT>
 static hipError_t launchWavefrontT(const RenderArgs& a, int blocks, int threads, size_t shmem, hipStream_t stream) {
     if (LDS)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(renderWavefront<LDS, COUNT, SPLIT>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(renderWavefront<LDS, COUNT>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    renderWavefront<LDS, COUNT, SPLIT><<<blocks, threads, shmem, stream>>>(a);
-    return hipGetLastError();
-}
-
-template <bool LDS, bool COUNT>
-static hipError_t launchWavefrontS(const RenderArgs& a, int blocks, int threads, size_t shmem, hipStream_t stream) {
-    if (!a.colors) return launchWavefrontT<LDS, COUNT, false>(a, blocks, threads, shmem, stream);
-    hipError_t e = launchWavefrontT<LDS, COUNT, true>(a, blocks, threads, shmem, stream);
+    renderWavefront<LDS, COUNT><<<blocks, threads, shmem, stream>>>(a);
+    hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const int nSlots = a.n_local_tiles * 64;
     accumulateColors<<<(nSlots + 255) / 256, 256, 0, stream>>>(a);
@@ -1126,10 +1096,10 @@ static hipError_t launchWavefrontS(const RenderArgs& a, int blocks, int threads,
 
 hipError_t launchWavefront(const RenderArgs& a, bool lds, bool count, int blocks, int threads, hipStream_t stream) {
     size_t shmem = lds ? (size_t)a.lds_bytes : 0;
-    if (lds) return count ? launchWavefrontS<true, true>(a, blocks, threads, shmem, stream)
-                          : launchWavefrontS<true, false>(a, blocks, threads, shmem, stream);
-    return count ? launchWavefrontS<false, true>(a, blocks, threads, 0, stream)
-                 : launchWavefrontS<false, false>(a, blocks, threads, 0, stream);
+    if (lds) return count ? launchWavefrontT<true, true>(a, blocks, threads, shmem, stream)
+                          : launchWavefrontT<true, false>(a, blocks, threads, shmem, stream);
+    return count ? launchWavefrontT<false, true>(a, blocks, threads, 0, stream)
+                 : launchWavefrontT<false, false>(a, blocks, threads, 0, stream);
 }
 
 hipError_t launchRender(const RenderArgs& a, bool lds, bool count, int blocks, int threads, hipStream_t stream) {
