@@ -74,6 +74,7 @@ int fail(int code, const std::string& msg) {
 // Largest LDS footprint the staged-scene kernel is allowed to ask for.  Two such workgroups
 // still fit the 160 KiB of a CU.
 constexpr size_t kMaxLdsScene = 72 * 1024;
+constexpr size_t kLdsThreeGroups = 52 * 1024;
 
 int envInt(const char* name, int dflt) {
     const char* v = std::getenv(name);
@@ -158,11 +159,11 @@ int launch(rt_context* ctx, rt::RenderArgs& a, bool count) {
     a.knob[0] = envInt("RT_BOX_KEEP", 8);
     a.knob[1] = envInt("RT_SHADE_MIN", 32);
     int wfThreads = envInt("RT_THREADS", 512);
-    if (wfThreads < 64 || wfThreads > 1024 || wfThreads % 64 != 0) wfThreads = 512;
+    if (wfThreads < 64 || wfThreads > 512 || wfThreads % 64 != 0) wfThreads = 512;
     const int wfWaves = wfThreads / 64;
-    // two 512-thread workgroups per CU = 4 waves per SIMD: measured best (a scene staged in LDS
-    // leaves room for two workgroups; more waves per SIMD ran slower, fewer too)
-    const int maxBlocks = ctx->n_cus * envInt("RT_BLOCKS_PER_CU", 2);
+    // three 512-thread workgroups per CU = 6 waves per SIMD (two when the staged scene is too big)
+    const int perCu = ctx->use_lds && ctx->lds_need > kLdsThreeGroups ? 2 : 3;
+    const int maxBlocks = ctx->n_cus * envInt("RT_BLOCKS_PER_CU", perCu);
 
     // The kernel writes one radiance per pixel sample into the colour buffer and a second kernel
     // adds them per pixel in sample order; launches are cut so that the buffer stays within
@@ -513,12 +514,18 @@ int rt_upload_scene(rt_context* ctx, rt_scene* s) {
     std::memcpy(d.cam, &sc.camera, sizeof(float) * 22);
     std::memcpy(d.bg, sc.background, sizeof(float) * 3);
     ctx->dsc = d;
-    // Scene tables in LDS when they fit: all of them, else all but the reference-order arrays
-    // (measured equally fast: those are touched once or twice per accepted hit), else none.
-    // RT_LDS overrides: 0 = global memory, 1 = all tables or nothing, 2 = without the reference arrays.
+    // Scene tables in LDS when they fit.  Three workgroups share a CU's 160 KiB, so the preferred
+    // footprint is at most kLdsThreeGroups: all tables if that fits, else all but the
+    // reference-order arrays (touched once or twice per accepted hit and by the rare re-trace);
+    // failing that, up to kMaxLdsScene with two workgroups per CU; else global memory.
+    // RT_LDS overrides: 0 = global memory, 1 = all tables, 2 = without the reference arrays.
     const int ldsMode = envInt("RT_LDS", -1);
-    ctx->lds_refs = ldsMode == 1 || (ldsMode < 0 && rt::ldsSceneBytes(d, true) <= kMaxLdsScene);
-    ctx->lds_need = rt::ldsSceneBytes(d, ctx->lds_refs);
+    const size_t all = rt::ldsSceneBytes(d, true), part = rt::ldsSceneBytes(d, false);
+    if (ldsMode == 1 || ldsMode == 2)
+        ctx->lds_refs = ldsMode == 1;
+    else
+        ctx->lds_refs = all <= kLdsThreeGroups || (part > kLdsThreeGroups && all <= kMaxLdsScene);
+    ctx->lds_need = ctx->lds_refs ? all : part;
     ctx->use_lds = ctx->lds_need <= kMaxLdsScene && ldsMode != 0;
     ctx->scene_loaded = true;
     return RT_OK;
