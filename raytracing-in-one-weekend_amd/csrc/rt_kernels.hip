@@ -810,13 +810,10 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
                     const int first = (int)fbits(n1.w);
                     if (COUNT) st.v[C_NODE]++;
                     const bool pass = slabPassFast(n0, n1, invx, invy, invz, nox, noy, noz, h.t);
+                    const bool leaf = pass && first >= 0;
                     idx = pass ? idx + 1 : (int)fbits(n1.z);
-                    if (pass && first >= 0) {
-                        p = first;
-                        op = OP_PRIM;
-                    } else if (idx >= nNodesFast) {
-                        op = OP_SHADE;
-                    }
+                    p = leaf ? first : p;
+                    op = leaf ? OP_PRIM : (idx >= nNodesFast ? OP_SHADE : OP_BOX);
                 }
             } while (popc64(__ballot(op == OP_BOX)) >= keep && keep > 0);
         } else if (chosen == OP_REFBOX) {
