@@ -1,12 +1,9 @@
 """Kernel time of ONE rank's share of the bench frame for several world sizes, on one GPU:
 rank 0 of `world` owns 1/world of the 8x8 tiles and renders 64*world samples per pixel (the
-bench's weak-scaling step), with whole-pixel work units (RT_SPLIT=0) and with sample-chunk units
-(RT_SPLIT=1).  Also checks that both give identical bits.
+bench's weak-scaling step).  Shows that a rank's time does not depend on how few pixels it owns.
 Usage: python profiles/rank_share.py [world ...]"""
 import os
 import sys
-
-import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from __graft_entry__ import load_package
@@ -23,16 +20,10 @@ ctx.upload_scene(s)
 for world in worlds:
     ctx.set_target(W, H, 0, world)
     spp = 64 * world
-    out = {}
-    for split in ("0", "1", "-1"):
-        os.environ["RT_SPLIT"] = split
-        ms = []
-        for _ in range(3):
-            ctx.clear()
-            ctx.render(0, spp, 50)
-            ctx.sync()
-            ms.append(ctx.last_render_ms())
-        out[split] = (min(ms), ctx.read_accum())
-    same = np.array_equal(out["0"][1].view(np.uint32), out["1"][1].view(np.uint32))
-    print(f"world {world}: {spp} spp on 1/{world} of the tiles: whole pixels {out['0'][0]:.2f} ms, "
-          f"sample chunks {out['1'][0]:.2f} ms, automatic {out['-1'][0]:.2f} ms, identical bits: {same}", flush=True)
+    ms = []
+    for _ in range(3):
+        ctx.clear()
+        ctx.render(0, spp, 50)
+        ctx.sync()
+        ms.append(ctx.last_render_ms())
+    print(f"world {world}: {spp} spp on 1/{world} of the tiles: {min(ms):.2f} ms", flush=True)

@@ -1,8 +1,9 @@
 """Writes profiles/hbm_traffic.json from the FETCH_SIZE / WRITE_SIZE passes of profiles/run_profile.sh.
 
 rocprofv3 reports both counters in kilobytes.  On gfx950 FETCH_SIZE tallies the 128-byte read
-requests of wide coalesced loads (16 B per lane, the accumulation-buffer reads here) at 64 bytes,
-so it is doubled; WRITE_SIZE is exact for 16-B-per-lane stores.  bytes = (2 * fetch + write) * 1024.
+requests of wide coalesced loads (16 B per lane: the colour-buffer and accumulation-buffer reads
+here) at 64 bytes, so it is doubled; WRITE_SIZE is exact for 16-B-per-lane stores.
+bytes = (2 * fetch + write) * 1024, render kernel + ordered-sum kernel of one launch.
 Usage: python profiles/summarize_traffic.py gpurun_out/prof_<tag>"""
 import glob
 import json
@@ -12,16 +13,23 @@ import sys
 
 
 def per_dispatch(root, counter):
+    """Average per dispatch of the render kernel plus average per dispatch of the ordered-sum kernel
+    that follows every render launch."""
     for db_path in sorted(glob.glob(os.path.join(root, "*", "*_results.db"))):
         cur = sqlite3.connect(db_path).cursor()
-        try:
-            rows = list(cur.execute(
-                "select sum(value) / count(distinct dispatch_id) from counters_collection "
-                "where counter_name = ? and kernel_name like '%renderWavefront<true, false>%'", (counter,)))
-        except sqlite3.Error:
-            continue
-        if rows and rows[0][0] is not None:
-            return float(rows[0][0])
+        total, found = 0.0, False
+        for pattern in ("%renderWavefront<true, false>%", "%accumulateColors%"):
+            try:
+                rows = list(cur.execute(
+                    "select sum(value) / count(distinct dispatch_id) from counters_collection "
+                    "where counter_name = ? and kernel_name like ?", (counter, pattern)))
+            except sqlite3.Error:
+                rows = []
+            if rows and rows[0][0] is not None:
+                total += float(rows[0][0])
+                found = True
+        if found:
+            return total
     return None
 
 
