@@ -796,26 +796,60 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
             schedExec[slot] += 1;
             schedLanes[slot] += cnt[chosen];
         }
-        if (chosen == OP_BOX) {
-            // Search structure: conservative fused box test.  An entry that passes and carries a
-            // leaf run sends the lane to PRIM; `idx` already names the entry to go on with.
-            const int keep = boxKeep < cBox ? boxKeep : cBox;  // never spin below what is available
-            do {
+        if (chosen == OP_BOX || chosen == OP_PRIM) {
+            // Traversal phase: box bursts and primitive tests alternate, with a two-ballot vote
+            // between them, for as long as one of the two has more lanes waiting than all the
+            // other operations together; then back to the full vote.
+            const int total = cBox + cPrim + cShade + cPath + cRef;  // lanes that are not done
+            int nBox = cBox, cur = chosen;
+            for (;;) {
+                if (cur == OP_BOX) {
+                    // Search structure: conservative fused box test.  An entry that passes and carries
+                    // a leaf run sends the lane to PRIM; `idx` already names the entry to go on with.
+                    const int keep = boxKeep < nBox ? boxKeep : nBox;  // never spin below what is available
+                    do {
+                        if (COUNT) {
+                            schedExec[5] += 1;
+                            schedLanes[5] += popc64(__ballot(op == OP_BOX));
+                        }
+                        if (op == OP_BOX) {
+                            const float4 n0 = sv.fnodes[2 * idx], n1 = sv.fnodes[2 * idx + 1];
+                            const int first = (int)fbits(n1.w);
+                            if (COUNT) st.v[C_NODE]++;
+                            const bool pass = slabPassFast(n0, n1, invx, invy, invz, nox, noy, noz, h.t);
+                            const bool leaf = pass && first >= 0;
+                            idx = pass ? idx + 1 : (int)fbits(n1.z);
+                            p = leaf ? first : p;
+                            op = leaf ? OP_PRIM : (idx >= nNodesFast ? OP_SHADE : OP_BOX);
+                        }
+                    } while (popc64(__ballot(op == OP_BOX)) >= keep && keep > 0);
+                } else if (op == OP_PRIM) {
+                    const uint32_t ref = (mode ? sv.refs : sv.frefs)[p];
+                    bool bad = false;
+                    if (mode) {
+                        primRef<COUNT>(sv, ref, r, aa, h, &st);
+                    } else {
+                        primAnyOrder<COUNT>(sv, ref, r, aa, h, bad, &st);
+                    }
+                    if (bad) {
+                        retraceInReferenceOrder();
+                    } else if (ref & kRefLast) {
+                        op = idx >= (mode ? nNodesRef : nNodesFast) ? OP_SHADE : (mode ? OP_REFBOX : OP_BOX);
+                    } else {
+                        p += 1;
+                    }
+                }
+                nBox = popc64(__ballot(op == OP_BOX));
+                const int nPrim = popc64(__ballot(op == OP_PRIM));
+                const int others = total - nBox - nPrim;
+                const int best = nBox > nPrim ? nBox : nPrim;
+                if (best == 0 || others >= shadeMin || best < others) break;
+                cur = nBox >= nPrim ? OP_BOX : OP_PRIM;
                 if (COUNT) {
-                    schedExec[5] += 1;
-                    schedLanes[5] += popc64(__ballot(op == OP_BOX));
+                    schedExec[cur] += 1;
+                    schedLanes[cur] += best;
                 }
-                if (op == OP_BOX) {
-                    const float4 n0 = sv.fnodes[2 * idx], n1 = sv.fnodes[2 * idx + 1];
-                    const int first = (int)fbits(n1.w);
-                    if (COUNT) st.v[C_NODE]++;
-                    const bool pass = slabPassFast(n0, n1, invx, invy, invz, nox, noy, noz, h.t);
-                    const bool leaf = pass && first >= 0;
-                    idx = pass ? idx + 1 : (int)fbits(n1.z);
-                    p = leaf ? first : p;
-                    op = leaf ? OP_PRIM : (idx >= nNodesFast ? OP_SHADE : OP_BOX);
-                }
-            } while (popc64(__ballot(op == OP_BOX)) >= keep && keep > 0);
+            }
         } else if (chosen == OP_REFBOX) {
             // Reference-order array: the reference's own test; list entries have no box.
             const int keep = boxKeep < cRef ? boxKeep : cRef;
@@ -840,23 +874,6 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
                     }
                 }
             } while (popc64(__ballot(op == OP_REFBOX)) >= keep && keep > 0);
-        } else if (chosen == OP_PRIM) {
-            if (op == OP_PRIM) {
-                const uint32_t ref = (mode ? sv.refs : sv.frefs)[p];
-                bool bad = false;
-                if (mode) {
-                    primRef<COUNT>(sv, ref, r, aa, h, &st);
-                } else {
-                    primAnyOrder<COUNT>(sv, ref, r, aa, h, bad, &st);
-                }
-                if (bad) {
-                    retraceInReferenceOrder();
-                } else if (ref & kRefLast) {
-                    op = idx >= (mode ? nNodesRef : nNodesFast) ? OP_SHADE : (mode ? OP_REFBOX : OP_BOX);
-                } else {
-                    p += 1;
-                }
-            }
         } else if (chosen == OP_SHADE) {
             if (op == OP_SHADE) {
                 if (h.ref == kNoHit) {
