@@ -24,6 +24,7 @@
 // monotonicity argument).
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 
@@ -59,7 +60,7 @@ struct Builder {
     std::vector<uint32_t>& nodes;
     std::vector<uint32_t>& refs;
     static constexpr int kBins = 16;
-    static constexpr int kMaxLeaf = 2;
+    int kMaxLeaf = 2;
 
     int newEntry(const float* mn, const float* mx) {
         int idx = (int)(nodes.size() / 8);
@@ -292,6 +293,7 @@ void Scene::buildFastStructure() {
         return;
     }
     Builder bld{prims, f.fast_nodes, f.fast_refs};
+    if (const char* e = std::getenv("RT_FAST_LEAF")) bld.kMaxLeaf = std::max(1, std::atoi(e));
     bld.build(0, prims.size());
 }
 
