@@ -174,7 +174,11 @@ int rt_clear(rt_context* ctx);
  * accumulation buffer: the pixel loops of RaytracerNormal::Run / RaytracerMT::writeLine
  * (R/src/Core/Raytracer.cpp:46-132) with rayColor (Raytracer.cpp:3-20) for each sample.
  * Random numbers are the reference shader's stateless hash keyed (x, y, sample, counter)
- * (R/assets/shaders/raytracer.comp:35-54).  Asynchronous on the context's stream. */
+ * (R/assets/shaders/raytracer.comp:35-54).  Every sample's radiance passes through a device
+ * colour buffer (16 bytes per pixel sample of the launch, allocated on first use and grown on
+ * demand; calls that would need more than RT_COLORS_MB megabytes, default 4096, run as several
+ * launches) and is added per pixel in sample order, so the sums have the bits of the reference's
+ * sequential `pixelColor +=`.  Asynchronous on the context's stream unless the buffer must grow. */
 int rt_render(rt_context* ctx, int first_sample, int n_samples, int max_depth);
 /* Blocks until the stream is idle (the join in runRaytracer(), RaytracingApplication.cpp:269). */
 int rt_sync(rt_context* ctx);
@@ -239,8 +243,8 @@ int rt_count(rt_context* ctx, int first_sample, int n_samples, int max_depth, rt
  * votes, then the votes for the reference-order box test.  No reference counterpart. */
 int rt_sched_stats(rt_context* ctx, uint64_t* out14);
 
-/* Milliseconds the last rt_render() kernel took on the device (HIP events on the context's
- * stream).  Blocks until that kernel has finished. */
+/* Milliseconds the kernels of the last rt_render() took on the device (HIP events on the
+ * context's stream around the render and ordered-sum kernels).  Blocks until they have finished. */
 int rt_last_render_ms(rt_context* ctx, float* ms);
 /* The context's hipStream_t, for callers that order their own work after rt_render(). */
 void* rt_stream(rt_context* ctx);

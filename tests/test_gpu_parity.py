@@ -314,6 +314,19 @@ def test_cornell_box_lights_only(rt, orc, scenes, gpu_ctx):
     assert {k: cnt[k] for k in ocnt} == ocnt
 
 
+def test_colour_buffer_budget_cuts_launches_without_changing_bits(rt, scenes, gpu_ctx, monkeypatch):
+    """A render call whose per-sample colour buffer would exceed the budget is run as several
+    launches over consecutive sample ranges; the ordered per-pixel sum gives the same bits."""
+    w, h, spp = 200, 112, 100
+    a = rt.Scene()
+    scenes.cover_scene(a, w, h)
+    gpu_ctx.upload_scene(a)
+    whole = render_gpu(gpu_ctx, w, h, 0, spp)
+    monkeypatch.setenv("RT_COLORS_MB", "16")     # 16 MB / (22,400 pixel slots x 16 B) = 46 samples per launch
+    cut = render_gpu(gpu_ctx, w, h, 0, spp)
+    assert np.array_equal(bits(cut), bits(whole))
+
+
 def test_progressive_accumulation_is_split_invariant(rt, scenes, gpu_ctx):
     w, h = 160, 90
     a = rt.Scene()
