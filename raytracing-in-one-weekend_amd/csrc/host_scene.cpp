@@ -377,34 +377,38 @@ Box3 Scene::objectBox(const Obj& o) const {
 // pre-order (leaves included); std::sort on the node's own sub-range (a child only ever reads
 // its own sub-range of the parent's sorted copy, so sorting in place is equivalent);
 // mid = start + span/2; max_depth == 0 turns the halves into plain lists.
-int Scene::buildBvh(Composite& c, std::vector<Obj>& objs, size_t start, size_t end, int max_depth) {
+// The objects travel with their bounding boxes, computed once: boxCompare (Bvh.cpp:3-12) calls
+// BoundingBox() on both operands of every comparison, and std::sort's permutation depends only
+// on the outcomes of the comparisons, which are the same on the stored boxes.
+int Scene::buildBvh(Composite& c, std::vector<BoxedObj>& objs, size_t start, size_t end, int max_depth) {
     int axis = randomInt(0, 2);
-    // boxCompare, R/src/AccelerationStructures/Bvh.cpp:3-12
-    auto less = [this, axis](const Obj& a, const Obj& b) { return objectBox(a).mn[axis] < objectBox(b).mn[axis]; };
+    auto less = [axis](const BoxedObj& a, const BoxedObj& b) { return a.box.mn[axis] < b.box.mn[axis]; };
     int me = (int)c.nodes.size();
     c.nodes.emplace_back();
     size_t span = end - start;
     Box3 bl, br;
     if (span == 1) {
         // left = right = object: Hit() tests it twice with the same outcome; kept once
-        c.nodes[me].leaf = {objs[start]};
-        bl = br = objectBox(objs[start]);
+        c.nodes[me].leaf = {objs[start].obj};
+        bl = br = objs[start].box;
     } else if (span == 2) {
-        Obj a = objs[start], b = objs[start + 1];
+        BoxedObj a = objs[start], b = objs[start + 1];
         if (!less(a, b)) std::swap(a, b);
-        c.nodes[me].leaf = {a, b};
-        bl = objectBox(a);
-        br = objectBox(b);
+        c.nodes[me].leaf = {a.obj, b.obj};
+        bl = a.box;
+        br = b.box;
     } else {
         std::sort(objs.begin() + start, objs.begin() + end, less);
         size_t mid = start + span / 2;
         if (max_depth == 0) {
             // two HittableLists; HittableList::BoundingBox folds surroundingBox left to right
-            std::vector<Obj> leaf(objs.begin() + start, objs.begin() + end);
-            bl = objectBox(objs[start]);
-            for (size_t i = start + 1; i < mid; i++) bl = unionBox(bl, objectBox(objs[i]));
-            br = objectBox(objs[mid]);
-            for (size_t i = mid + 1; i < end; i++) br = unionBox(br, objectBox(objs[i]));
+            std::vector<Obj> leaf;
+            leaf.reserve(span);
+            for (size_t i = start; i < end; i++) leaf.push_back(objs[i].obj);
+            bl = objs[start].box;
+            for (size_t i = start + 1; i < mid; i++) bl = unionBox(bl, objs[i].box);
+            br = objs[mid].box;
+            for (size_t i = mid + 1; i < end; i++) br = unionBox(br, objs[i].box);
             c.nodes[me].leaf = std::move(leaf);
         } else {
             int l = buildBvh(c, objs, start, mid, max_depth - 1);
@@ -419,12 +423,19 @@ int Scene::buildBvh(Composite& c, std::vector<Obj>& objs, size_t start, size_t e
     return me;
 }
 
+std::vector<Scene::BoxedObj> Scene::withBoxes(const std::vector<Obj>& objs) const {
+    std::vector<BoxedObj> out;
+    out.reserve(objs.size());
+    for (const Obj& o : objs) out.push_back({o, objectBox(o)});
+    return out;
+}
+
 // world = HittableList(make_shared<BVHNode>(world)): Bvh.h:17, unlimited depth.
 void Scene::wrapBvh() {
     Composite c;
     c.kind = Composite::BVH;
     c.has_box_test = true;
-    std::vector<Obj> objs = world;
+    std::vector<BoxedObj> objs = withBoxes(world);
     c.root = buildBvh(c, objs, 0, objs.size(), -1);
     c.box = c.nodes[c.root].box;
     composites.push_back(std::move(c));
@@ -482,7 +493,8 @@ int Scene::addMesh(const float* model16, int n_vertices, const float* positions,
     Composite bvh;
     bvh.kind = Composite::BVH;
     bvh.has_box_test = true;
-    bvh.root = buildBvh(bvh, tris, 0, tris.size(), max_depth);
+    std::vector<BoxedObj> boxed = withBoxes(tris);
+    bvh.root = buildBvh(bvh, boxed, 0, boxed.size(), max_depth);
     bvh.box = bvh.nodes[bvh.root].box;
     composites.push_back(std::move(bvh));
     mesh.objs.push_back({Obj::COMPOSITE, (int)composites.size() - 1});

@@ -122,7 +122,12 @@ public:
 
 private:
     int newTriangle(const float* pos9, const float* nrm9, const float* uv6, int mat);
-    int buildBvh(Composite& c, std::vector<Obj>& objs, size_t start, size_t end, int max_depth);
+    struct BoxedObj {
+        Obj obj;
+        Box3 box;
+    };
+    std::vector<BoxedObj> withBoxes(const std::vector<Obj>& objs) const;
+    int buildBvh(Composite& c, std::vector<BoxedObj>& objs, size_t start, size_t end, int max_depth);
     void emitObjects(const std::vector<Obj>& objs, int parent_entry);
     void emitComposite(const Composite& c);
     void emitBvhNode(const Composite& c, int node);
