@@ -927,29 +927,32 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
                     chunkInside = tx < a.tiles_x;
                 }
             }
-            const int rankInMask = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-            const int l = chunkNext + rankInMask;  // pixel inside the tile
-            const int px = chunkX0 + (l & 7), py = chunkY0 + (l >> 3);
-            // a lane beyond the chunk's 64 pixels, or on a pixel outside the image, asks again
-            const bool got = want && chunk >= 0 && l < 64;
-            const bool pixel = got && chunkInside && px < a.width && py < a.height;
-            const bool go = pixel && a.max_depth > 0;
-            op = (want && chunk < 0) ? OP_DONE : op;
-            unit = got ? (unsigned int)chunk * 64u + (unsigned int)l : unit;
-            if (COUNT && pixel) st.v[C_SAMPLES]++;
-            if (pixel && !go) {  // max depth <= 0: the path ends before its first ray
-                if (COUNT) st.v[C_CUTOFF]++;
-                a.colors[unit] = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-            if (go) {
-                rng.init((uint32_t)px, (uint32_t)py, chunkSample);
-                // u is drawn before v (R/src/Core/Raytracer.cpp:86-87)
-                const float u = ((float)px + rng.next()) / (float)(a.width - 1);
-                const float v = ((float)py + rng.next()) / (float)(a.height - 1);
-                r = cameraRay(sc, u, v, rng);
-                thr = V3{1.0f, 1.0f, 1.0f};
-                depth = a.max_depth;
-                startRay();
+            if (want) {
+                const int rankInMask =
+                    __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                const int l = chunkNext + rankInMask;  // pixel inside the tile
+                if (chunk < 0) {
+                    op = OP_DONE;
+                } else if (l < 64) {
+                    const int px = chunkX0 + (l & 7), py = chunkY0 + (l >> 3);
+                    unit = (unsigned int)chunk * 64u + (unsigned int)l;
+                    if (chunkInside && px < a.width && py < a.height) {
+                        rng.init((uint32_t)px, (uint32_t)py, chunkSample);
+                        if (COUNT) st.v[C_SAMPLES]++;
+                        // u is drawn before v (R/src/Core/Raytracer.cpp:86-87)
+                        float u = ((float)px + rng.next()) / (float)(a.width - 1);
+                        float v = ((float)py + rng.next()) / (float)(a.height - 1);
+                        r = cameraRay(sc, u, v, rng);
+                        thr = V3{1.0f, 1.0f, 1.0f};
+                        depth = a.max_depth;
+                        if (depth <= 0) {
+                            if (COUNT) st.v[C_CUTOFF]++;
+                            endPath(V3{0.0f, 0.0f, 0.0f});
+                        } else {
+                            startRay();
+                        }
+                    }  // else not a pixel of the image: this lane asks again
+                }      // else the chunk ran out before this lane's turn: it asks again
             }
             chunkNext += popc64(m);
         }
