@@ -807,7 +807,7 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
                     // Search structure: conservative fused box test.  An entry that passes and carries
                     // a leaf run sends the lane to PRIM; `idx` already names the entry to go on with.
                     const int keep = boxKeep < nBox ? boxKeep : nBox;  // never spin below what is available
-                    do {
+                    auto boxStep = [&]() {
                         if (COUNT) {
                             schedExec[5] += 1;
                             schedLanes[5] += popc64(__ballot(op == OP_BOX));
@@ -822,6 +822,11 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
                             p = leaf ? first : p;
                             op = leaf ? OP_PRIM : (idx >= nNodesFast ? OP_SHADE : OP_BOX);
                         }
+                    };
+                    do {  // three steps per look at the lane count (1: 32.35 ms, 2: 31.75, 3: 31.6, 4: 31.7)
+                        boxStep();
+                        boxStep();
+                        boxStep();
                     } while (popc64(__ballot(op == OP_BOX)) >= keep && keep > 0);
                 } else if (op == OP_PRIM) {
                     const uint32_t ref = (mode ? sv.refs : sv.frefs)[p];
