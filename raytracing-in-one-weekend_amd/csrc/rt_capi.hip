@@ -487,14 +487,6 @@ int rt_upload_scene(rt_context* ctx, rt_scene* s) {
     if ((rc = devUpload(ctx, sc.flat.prim_refs, &d.prim_refs))) return rc;
     std::vector<float4> fastNodes(sc.flat.fast_nodes.size() / 4);
     std::memcpy(fastNodes.data(), sc.flat.fast_nodes.data(), sc.flat.fast_nodes.size() * 4);
-    // on the device the search structure's skip links are byte offsets (entry index x 32)
-    if (fastNodes.size() / 2 >= (size_t)(1u << 26)) return fail(RT_ERR_LIMIT, "too many search-structure entries");
-    for (size_t e = 0; e < fastNodes.size() / 2; e++) {
-        uint32_t skip;
-        std::memcpy(&skip, &fastNodes[2 * e + 1].z, 4);
-        skip *= 32u;
-        std::memcpy(&fastNodes[2 * e + 1].z, &skip, 4);
-    }
     if ((rc = devUpload(ctx, fastNodes, &d.fast_nodes))) return rc;
     if ((rc = devUpload(ctx, sc.flat.fast_refs, &d.fast_refs))) return rc;
     if ((rc = devUpload(ctx, sc.flat.sphere_ord, &d.sphere_ord))) return rc;

@@ -12,7 +12,7 @@ struct DevScene {
     const float4* nodes;      // 2 x float4 per entry: {min.xyz, skip|flags}, {max.xyz, first_ref}
     const uint32_t* prim_refs;
     // search structure traversed first (same entry format, padded boxes) and its guard data
-    const float4* fast_nodes;  // {min.x, max.x, min.y, max.y}, {min.z, max.z, skip link as a BYTE offset, first_ref}
+    const float4* fast_nodes;
     const uint32_t* fast_refs;
     const int* sphere_ord;    // sphere id   -> position in prim_refs (the reference's visit order)
     const int* tri_ord;       // triangle id -> position in prim_refs

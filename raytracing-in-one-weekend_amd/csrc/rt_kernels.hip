@@ -285,14 +285,6 @@ __device__ __forceinline__ Hit traverseRef(const SceneView& sv, int n_nodes, con
     return h;
 }
 
-// Entry of the search structure at byte offset `off` (its links are byte offsets too, so that a
-// step needs no index arithmetic; with the tables in LDS the array's base folds into the load).
-__device__ __forceinline__ void fastEntry(const SceneView& sv, int off, float4& n0, float4& n1) {
-    const float4* e = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(sv.fnodes) + off);
-    n0 = e[0];
-    n1 = e[1];
-}
-
 // The same walk over the search structure: tighter tree, padded boxes, conservative box test,
 // order-independent update.
 template <bool COUNT>
@@ -300,11 +292,9 @@ __device__ __forceinline__ Hit traverseFast(const SceneView& sv, int n_nodes, co
                                             float a, bool& bad, Stats* st) {
     Hit h{__builtin_inff(), kNoHit, 0.0f, 0.0f};
     const float nox = -(r.o.x * invx), noy = -(r.o.y * invy), noz = -(r.o.z * invz);
-    int idx = 0;  // byte offset of the entry
-    const int end = n_nodes * 32;
-    while (idx < end) {
-        float4 n0, n1;
-        fastEntry(sv, idx, n0, n1);
+    int idx = 0;
+    while (idx < n_nodes) {
+        const float4 n0 = sv.fnodes[2 * idx], n1 = sv.fnodes[2 * idx + 1];
         const int first = (int)fbits(n1.w);
         if (COUNT) st->v[C_NODE]++;
         if (slabPassFast(n0, n1, invx, invy, invz, nox, noy, noz, h.t)) {
@@ -316,7 +306,7 @@ __device__ __forceinline__ Hit traverseFast(const SceneView& sv, int n_nodes, co
                     primAnyOrder<COUNT>(sv, ref, r, a, h, bad, st);
                 } while (!(ref & kRefLast));
             }
-            idx = idx + 32;
+            idx = idx + 1;
         } else {
             idx = (int)fbits(n1.z);
         }
@@ -722,8 +712,7 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
         sv = globalView(sc);
     }
     const int lane = threadIdx.x & 63;
-    // `idx` is an entry index in the reference-order array and a byte offset in the search structure
-    const int nNodesRef = sc.n_nodes, nNodesFast = sc.n_fast_nodes * 32;
+    const int nNodesRef = sc.n_nodes, nNodesFast = sc.n_fast_nodes;
     const int nTiles = a.n_local_tiles;
     const unsigned int nChunks = (unsigned int)nTiles * (unsigned int)a.n_samples;  // 64 units each
     const int boxKeep = a.knob[0];    // keep running BOX steps while at least this many lanes want one
@@ -824,13 +813,12 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
                             schedLanes[5] += popc64(__ballot(op == OP_BOX));
                         }
                         if (op == OP_BOX) {
-                            float4 n0, n1;
-                            fastEntry(sv, idx, n0, n1);
+                            const float4 n0 = sv.fnodes[2 * idx], n1 = sv.fnodes[2 * idx + 1];
                             const int first = (int)fbits(n1.w);
                             if (COUNT) st.v[C_NODE]++;
                             const bool pass = slabPassFast(n0, n1, invx, invy, invz, nox, noy, noz, h.t);
                             const bool leaf = pass && first >= 0;
-                            idx = pass ? idx + 32 : (int)fbits(n1.z);
+                            idx = pass ? idx + 1 : (int)fbits(n1.z);
                             p = leaf ? first : p;
                             op = leaf ? OP_PRIM : (idx >= nNodesFast ? OP_SHADE : OP_BOX);
                         }
