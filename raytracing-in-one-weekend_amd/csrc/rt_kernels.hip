@@ -828,21 +828,26 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
                         boxStep();
                         boxStep();
                     } while (popc64(__ballot(op == OP_BOX)) >= keep && keep > 0);
-                } else if (op == OP_PRIM) {
-                    const uint32_t ref = (mode ? sv.refs : sv.frefs)[p];
-                    bool bad = false;
-                    if (mode) {
-                        primRef<COUNT>(sv, ref, r, aa, h, &st);
-                    } else {
-                        primAnyOrder<COUNT>(sv, ref, r, aa, h, bad, &st);
-                    }
-                    if (bad) {
-                        retraceInReferenceOrder();
-                    } else if (ref & kRefLast) {
-                        op = idx >= (mode ? nNodesRef : nNodesFast) ? OP_SHADE : (mode ? OP_REFBOX : OP_BOX);
-                    } else {
-                        p += 1;
-                    }
+                } else {
+                    const int primKeep = a.knob[3];  // go on with the leaf runs while this many lanes have more
+                    do {
+                        if (op == OP_PRIM) {
+                            const uint32_t ref = (mode ? sv.refs : sv.frefs)[p];
+                            bool bad = false;
+                            if (mode) {
+                                primRef<COUNT>(sv, ref, r, aa, h, &st);
+                            } else {
+                                primAnyOrder<COUNT>(sv, ref, r, aa, h, bad, &st);
+                            }
+                            if (bad) {
+                                retraceInReferenceOrder();
+                            } else if (ref & kRefLast) {
+                                op = idx >= (mode ? nNodesRef : nNodesFast) ? OP_SHADE : (mode ? OP_REFBOX : OP_BOX);
+                            } else {
+                                p += 1;
+                            }
+                        }
+                    } while (popc64(__ballot(op == OP_PRIM)) >= primKeep);
                 }
                 nBox = popc64(__ballot(op == OP_BOX));
                 const int nPrim = popc64(__ballot(op == OP_PRIM));
