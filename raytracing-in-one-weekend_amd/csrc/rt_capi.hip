@@ -42,7 +42,7 @@ struct rt_context {
     bool scene_loaded = false;
     size_t lds_need = 0;
     bool use_lds = false;
-    int lds_level = 0;  // which tables are staged (ldsSceneBytes)
+    bool lds_refs = true;  // the reference-order arrays are staged too
     int n_cus = 256;
     int width = 0, height = 0, rank = 0, world = 1;
     int tiles_x = 0, tiles_y = 0, tprl = 0, n_local_tiles = 0;
@@ -73,8 +73,8 @@ int fail(int code, const std::string& msg) {
 
 // Largest LDS footprint the staged-scene kernel is allowed to ask for.  Two such workgroups
 // still fit the 160 KiB of a CU.
-constexpr size_t kMaxLdsScene = 72 * 1024 - 512 * 7 * 4;
-constexpr size_t kLdsThreeGroups = 52 * 1024 - 512 * 7 * 4;  // 14 KB per workgroup hold parked path state
+constexpr size_t kMaxLdsScene = 72 * 1024;
+constexpr size_t kLdsThreeGroups = 52 * 1024;
 
 int envInt(const char* name, int dflt) {
     const char* v = std::getenv(name);
@@ -129,7 +129,7 @@ rt::RenderArgs makeArgs(rt_context* ctx, int first_sample, int n_samples, int ma
     a.n_samples = n_samples;
     a.max_depth = max_depth;
     a.lds_bytes = (int)ctx->lds_need;
-    a.knob[2] = ctx->lds_level;
+    a.knob[2] = ctx->lds_refs ? 1 : 0;
     return a;
 }
 
@@ -316,7 +316,7 @@ int rt_scene_flatten(rt_scene* s, rt_flat_info* info) {
         d.n_spheres = info->n_spheres;
         d.n_tris = info->n_triangles;
         d.n_mats = info->n_materials;
-        info->fits_lds = rt::ldsSceneBytes(d, 2) <= kMaxLdsScene;  // at least the search tables and primitives
+        info->fits_lds = rt::ldsSceneBytes(d) <= kMaxLdsScene;
     }
     return RT_OK;
 }
@@ -516,21 +516,17 @@ int rt_upload_scene(rt_context* ctx, rt_scene* s) {
     std::memcpy(d.bg, sc.background, sizeof(float) * 3);
     ctx->dsc = d;
     // Scene tables in LDS when they fit.  Three workgroups share a CU's 160 KiB, so the preferred
-    // footprint is at most kLdsThreeGroups: every table if that fits, else without the
-    // reference-order arrays, else also without the material table; failing that, up to
-    // kMaxLdsScene with two workgroups per CU; else global memory.
-    // RT_LDS overrides: 0 = global memory, 1 / 2 / 3 = staging level 0 / 1 / 2.
+    // footprint is at most kLdsThreeGroups: all tables if that fits, else all but the
+    // reference-order arrays (touched once or twice per accepted hit and by the rare re-trace);
+    // failing that, up to kMaxLdsScene with two workgroups per CU; else global memory.
+    // RT_LDS overrides: 0 = global memory, 1 = all tables, 2 = without the reference arrays.
     const int ldsMode = envInt("RT_LDS", -1);
-    int level = 0;
-    if (ldsMode >= 1 && ldsMode <= 3) {
-        level = ldsMode - 1;
-    } else {
-        while (level < 2 && rt::ldsSceneBytes(d, level) > kLdsThreeGroups) level++;
-        if (rt::ldsSceneBytes(d, level) > kLdsThreeGroups)  // two workgroups per CU: stage as much as fits
-            for (level = 0; level < 2 && rt::ldsSceneBytes(d, level) > kMaxLdsScene;) level++;
-    }
-    ctx->lds_level = level;
-    ctx->lds_need = rt::ldsSceneBytes(d, level);
+    const size_t all = rt::ldsSceneBytes(d, true), part = rt::ldsSceneBytes(d, false);
+    if (ldsMode == 1 || ldsMode == 2)
+        ctx->lds_refs = ldsMode == 1;
+    else
+        ctx->lds_refs = all <= kLdsThreeGroups || (part > kLdsThreeGroups && all <= kMaxLdsScene);
+    ctx->lds_need = ctx->lds_refs ? all : part;
     ctx->use_lds = ctx->lds_need <= kMaxLdsScene && ldsMode != 0;
     ctx->scene_loaded = true;
     return RT_OK;

@@ -55,17 +55,15 @@ struct RenderArgs {
 constexpr int kTile = 8;  // one wave64 = one 8x8 pixel tile
 
 // Bytes of LDS the staged scene tables need, each block 16-byte aligned (order = stageScene()).
-// level 0: every table; level 1: without the reference-order entries, their leaf references and
-// the guard tables (touched once or twice per accepted hit and by the rare re-trace); level 2:
-// also without the material table (read once per shaded hit).  What is left out is read from
-// global memory, which lets one more workgroup share a CU's LDS.
-inline size_t ldsSceneBytes(const DevScene& s, int level = 0) {
+// with_reference_arrays = false leaves the reference-order entries, their leaf references and the
+// guard tables in global memory (they are touched once or twice per accepted hit and by the rare
+// re-trace), which lets one more workgroup share a CU's LDS.
+inline size_t ldsSceneBytes(const DevScene& s, bool with_reference_arrays = true) {
     auto al = [](size_t x) { return (x + 15) & ~size_t(15); };
     size_t n = al((size_t)s.n_fast_nodes * 32) + al((size_t)s.n_fast_refs * 4) + al((size_t)s.n_spheres * 16) +
                al((size_t)s.n_tris * 48) + al((size_t)s.n_spheres * 4) + al((size_t)s.n_tris * 4) +
-               al((size_t)s.n_spheres * 4) + al((size_t)s.n_tris * 4);
-    if (level < 2) n += al((size_t)s.n_mats * 32);
-    if (level < 1)
+               al((size_t)s.n_mats * 32) + al((size_t)s.n_spheres * 4) + al((size_t)s.n_tris * 4);
+    if (with_reference_arrays)
         n += al((size_t)s.n_nodes * 32) + al((size_t)s.n_prim_refs * 4) + al((size_t)s.n_prim_refs * 4) +
              al((size_t)s.n_nodes * 4);
     return n;

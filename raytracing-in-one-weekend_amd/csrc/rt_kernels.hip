@@ -555,7 +555,7 @@ __device__ __forceinline__ V3 rayColor(const DevScene& sc, const SceneView& sv, 
 extern __shared__ float4 rt_lds[];
 
 // Stages the scene tables into LDS and returns views into it (layout = ldsSceneBytes()).
-__device__ __forceinline__ SceneView stageScene(const DevScene& sc, int level) {
+__device__ __forceinline__ SceneView stageScene(const DevScene& sc, bool withReferenceArrays) {
     char* base = reinterpret_cast<char*>(rt_lds);
     int off = 0;
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -581,10 +581,10 @@ __device__ __forceinline__ SceneView stageScene(const DevScene& sc, int level) {
     v.tris = take16(sc.tri_isect, sc.n_tris * 3);
     v.sphere_mat = take4i(sc.sphere_mat, sc.n_spheres);
     v.tri_mat = take4i(sc.tri_mat, sc.n_tris);
+    v.materials = take16(sc.materials, sc.n_mats * 2);
     v.sphere_ord = take4i(sc.sphere_ord, sc.n_spheres);
     v.tri_ord = take4i(sc.tri_ord, sc.n_tris);
-    v.materials = level < 2 ? take16(sc.materials, sc.n_mats * 2) : sc.materials;
-    if (level < 1) {
+    if (withReferenceArrays) {
         v.nodes = take16(sc.nodes, sc.n_nodes * 2);
         v.refs = take4(sc.prim_refs, sc.n_prim_refs);
         v.prim_guard = take4i(sc.prim_guard, sc.n_prim_refs);
@@ -608,7 +608,7 @@ __global__ void __launch_bounds__(256) renderKernel(RenderArgs a) {
     fillCounterLut();
     SceneView sv;
     if (LDS) {
-        sv = stageScene(sc, a.knob[2]);
+        sv = stageScene(sc, a.knob[2] != 0);
     } else {
         sv = globalView(sc);
     }
@@ -686,7 +686,6 @@ __global__ void __launch_bounds__(256) renderKernel(RenderArgs a) {
 // what a path computes: the random stream is keyed by (x, y, sample, counter).
 // OP_BOX walks the search structure, OP_REFBOX the reference-order array (lanes with mode == 1).
 enum : int { OP_BOX = 0, OP_PRIM = 1, OP_SHADE = 2, OP_NEWPATH = 3, OP_REFBOX = 4, OP_DONE = 5 };
-constexpr int kParkDwords = 7;  // per lane: throughput (3), random stream (2), depth, work unit
 
 // Lanes set in a ballot mask, as a 32-bit scalar.  (__builtin_popcountll keeps the count 64 bits
 // wide, and every comparison between counts then goes through 64-bit vector compares.)
@@ -708,7 +707,7 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
     fillCounterLut();
     SceneView sv;
     if (LDS) {
-        sv = stageScene(sc, a.knob[2]);
+        sv = stageScene(sc, a.knob[2] != 0);
     } else {
         sv = globalView(sc);
     }
@@ -723,12 +722,10 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
         for (int i = 0; i < kNumStats; i++) st.v[i] = 0;
 
     int op = OP_NEWPATH;
-    int idx = 0, p = 0;
-    // The part of a path's state that only SHADE and NEWPATH touch -- throughput, random stream,
-    // remaining depth, work unit -- is parked in LDS between them (one dword column per value,
-    // indexed by thread), so that the traversal operations do not carry it in registers.
-    uint32_t* const park = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(rt_lds) + (LDS ? a.lds_bytes : 0)) + threadIdx.x;
-    const int parkStride = blockDim.x;
+    int depth = 0, idx = 0, p = 0;
+    unsigned int unit = 0;
+    V3 thr{1.f, 1.f, 1.f};
+    Rng rng{0u, 0u};
     Ray r{{0.f, 0.f, 0.f}, {0.f, 0.f, 1.f}};
     float invx = 0.f, invy = 0.f, invz = 0.f, aa = 1.f;
     float nox = 0.f, noy = 0.f, noz = 0.f;  // -origin / direction, for the search structure's box test
@@ -767,7 +764,7 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
         mode = 1;
         if (COUNT) st.v[C_FALLBACK]++;
     };
-    auto endPath = [&](V3 thr, unsigned int unit, V3 terminal) {
+    auto endPath = [&](V3 terminal) {
         const V3 c = thr * terminal;
         a.colors[unit] = make_float4(c.x, c.y, c.z, 0.f);
         op = OP_NEWPATH;
@@ -889,35 +886,26 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
             } while (popc64(__ballot(op == OP_REFBOX)) >= keep && keep > 0);
         } else if (chosen == OP_SHADE) {
             if (op == OP_SHADE) {
-                V3 thr{__uint_as_float(park[0]), __uint_as_float(park[parkStride]), __uint_as_float(park[2 * parkStride])};
-                const unsigned int unit = park[6 * parkStride];
                 if (h.ref == kNoHit) {
                     if (COUNT) st.v[C_MISS]++;
-                    endPath(thr, unit, V3{sc.bg[0], sc.bg[1], sc.bg[2]});
+                    endPath(V3{sc.bg[0], sc.bg[1], sc.bg[2]});
                 } else if (mode == 0 && !guardsPass<COUNT>(sv, r, invx, invy, invz, h, &st)) {
                     retraceInReferenceOrder();
                 } else {
                     if (COUNT) st.v[C_HITS]++;
-                    Rng rng{park[3 * parkStride], park[4 * parkStride]};
-                    int depth = (int)park[5 * parkStride];
                     Surface sf = surfaceAt(sc, sv, r, h);
                     Ray out;
                     V3 atten, emit;
                     if (!scatter<COUNT>(sc, sv, r, sf, rng, out, atten, emit, &st)) {
-                        endPath(thr, unit, emit);
+                        endPath(emit);
                     } else {
                         thr = thr * atten;
                         r = out;
                         depth -= 1;
                         if (depth <= 0) {
                             if (COUNT) st.v[C_CUTOFF]++;
-                            endPath(thr, unit, V3{0.0f, 0.0f, 0.0f});
+                            endPath(V3{0.0f, 0.0f, 0.0f});
                         } else {
-                            park[0] = fbits(thr.x);
-                            park[parkStride] = fbits(thr.y);
-                            park[2 * parkStride] = fbits(thr.z);
-                            park[4 * parkStride] = rng.counter;
-                            park[5 * parkStride] = (uint32_t)depth;
                             startRay();
                         }
                     }
@@ -957,25 +945,20 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
                     op = OP_DONE;
                 } else if (l < 64) {
                     const int px = chunkX0 + (l & 7), py = chunkY0 + (l >> 3);
-                    const unsigned int unit = (unsigned int)chunk * 64u + (unsigned int)l;
+                    unit = (unsigned int)chunk * 64u + (unsigned int)l;
                     if (chunkInside && px < a.width && py < a.height) {
-                        Rng rng;
                         rng.init((uint32_t)px, (uint32_t)py, chunkSample);
                         if (COUNT) st.v[C_SAMPLES]++;
                         // u is drawn before v (R/src/Core/Raytracer.cpp:86-87)
                         float u = ((float)px + rng.next()) / (float)(a.width - 1);
                         float v = ((float)py + rng.next()) / (float)(a.height - 1);
                         r = cameraRay(sc, u, v, rng);
-                        const V3 one{1.0f, 1.0f, 1.0f};
-                        if (a.max_depth <= 0) {
+                        thr = V3{1.0f, 1.0f, 1.0f};
+                        depth = a.max_depth;
+                        if (depth <= 0) {
                             if (COUNT) st.v[C_CUTOFF]++;
-                            endPath(one, unit, V3{0.0f, 0.0f, 0.0f});
+                            endPath(V3{0.0f, 0.0f, 0.0f});
                         } else {
-                            park[0] = park[parkStride] = park[2 * parkStride] = fbits(1.0f);
-                            park[3 * parkStride] = rng.key;
-                            park[4 * parkStride] = rng.counter;
-                            park[5 * parkStride] = (uint32_t)a.max_depth;
-                            park[6 * parkStride] = unit;
                             startRay();
                         }
                     }  // else not a pixel of the image: this lane asks again
@@ -1127,7 +1110,7 @@ __global__ void __launch_bounds__(256) resolveKernel(const float4* payloads, siz
 // ------------------------------------------------------------------ launch wrappers
 template <bool LDS, bool COUNT>
 static hipError_t launchWavefrontT(const RenderArgs& a, int blocks, int threads, size_t shmem, hipStream_t stream) {
-    if (shmem > 32 * 1024)
+    if (LDS)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(renderWavefront<LDS, COUNT>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     renderWavefront<LDS, COUNT><<<blocks, threads, shmem, stream>>>(a);
@@ -1139,11 +1122,11 @@ static hipError_t launchWavefrontT(const RenderArgs& a, int blocks, int threads,
 }
 
 hipError_t launchWavefront(const RenderArgs& a, bool lds, bool count, int blocks, int threads, hipStream_t stream) {
-    size_t shmem = (lds ? (size_t)a.lds_bytes : 0) + (size_t)threads * kParkDwords * 4;  // tables + parked path state
+    size_t shmem = lds ? (size_t)a.lds_bytes : 0;
     if (lds) return count ? launchWavefrontT<true, true>(a, blocks, threads, shmem, stream)
                           : launchWavefrontT<true, false>(a, blocks, threads, shmem, stream);
-    return count ? launchWavefrontT<false, true>(a, blocks, threads, shmem, stream)
-                 : launchWavefrontT<false, false>(a, blocks, threads, shmem, stream);
+    return count ? launchWavefrontT<false, true>(a, blocks, threads, 0, stream)
+                 : launchWavefrontT<false, false>(a, blocks, threads, 0, stream);
 }
 
 hipError_t launchRender(const RenderArgs& a, bool lds, bool count, int blocks, int threads, hipStream_t stream) {
