@@ -213,19 +213,6 @@ __device__ __forceinline__ bool primRoot(const SceneView& sv, uint32_t ref, cons
     return true;
 }
 
-// Barycentrics of a hit triangle again, with the expressions of the intersection test above (so
-// the same bits): lets a caller keep only (distance, primitive) between the test and the shading.
-__device__ __forceinline__ void triangleBarycentrics(const SceneView& sv, uint32_t id, const Ray& r, float& u, float& v) {
-    const float4 q0 = sv.tris[3 * id], q1 = sv.tris[3 * id + 1], q2 = sv.tris[3 * id + 2];
-    const V3 v0{q0.x, q0.y, q0.z}, e1{q1.x, q1.y, q1.z}, e2{q2.x, q2.y, q2.z};
-    const V3 hh = cross(r.d, e2);
-    const float f = 1.0f / dot(e1, hh);
-    const V3 s = r.o - v0;
-    u = f * dot(s, hh);
-    const V3 q = cross(s, e1);
-    v = f * dot(r.d, q);
-}
-
 // The reference's own update rule: primitives arrive in its visit order and each one is
 // tested against the running closest hit.
 template <bool COUNT>
@@ -740,13 +727,9 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
     V3 thr{1.f, 1.f, 1.f};
     Rng rng{0u, 0u};
     Ray r{{0.f, 0.f, 0.f}, {0.f, 0.f, 1.f}};
-    float invx = 0.f, invy = 0.f, invz = 0.f;
+    float invx = 0.f, invy = 0.f, invz = 0.f, aa = 1.f;
     float nox = 0.f, noy = 0.f, noz = 0.f;  // -origin / direction, for the search structure's box test
-    // closest hit so far: distance and primitive only (a triangle's barycentrics are computed
-    // again when it is shaded, dot(d, d) again for every primitive test: registers are scarcer
-    // than arithmetic here)
-    float hT = 0.f;
-    uint32_t hRef = kNoHit;
+    Hit h{0.f, kNoHit, 0.f, 0.f};
     // 0: the lane walks the search structure; 1: it walks the reference-order array (diagnostic
     // setting, zero direction component, or a re-trace after a failed guard test / NaN distance)
     int mode = 0;
@@ -762,8 +745,9 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
         invx = 1.0f / r.d.x;
         invy = 1.0f / r.d.y;
         invz = 1.0f / r.d.z;
-        hT = __builtin_inff();
-        hRef = kNoHit;
+        aa = dot(r.d, r.d);
+        h.t = __builtin_inff();
+        h.ref = kNoHit;
         idx = 0;
         nox = -(r.o.x * invx);
         noy = -(r.o.y * invy);
@@ -773,8 +757,8 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
         if (COUNT) st.v[C_RAYS]++;
     };
     auto retraceInReferenceOrder = [&]() {
-        hT = __builtin_inff();
-        hRef = kNoHit;
+        h.t = __builtin_inff();
+        h.ref = kNoHit;
         idx = 0;
         op = OP_REFBOX;
         mode = 1;
@@ -832,7 +816,7 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
                             const float4 n0 = sv.fnodes[2 * idx], n1 = sv.fnodes[2 * idx + 1];
                             const int first = (int)fbits(n1.w);
                             if (COUNT) st.v[C_NODE]++;
-                            const bool pass = slabPassFast(n0, n1, invx, invy, invz, nox, noy, noz, hT);
+                            const bool pass = slabPassFast(n0, n1, invx, invy, invz, nox, noy, noz, h.t);
                             const bool leaf = pass && first >= 0;
                             idx = pass ? idx + 1 : (int)fbits(n1.z);
                             p = leaf ? first : p;
@@ -849,16 +833,12 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
                     do {
                         if (op == OP_PRIM) {
                             const uint32_t ref = (mode ? sv.refs : sv.frefs)[p];
-                            const float aa = dot(r.d, r.d);
-                            Hit h{hT, hRef, 0.f, 0.f};
                             bool bad = false;
                             if (mode) {
                                 primRef<COUNT>(sv, ref, r, aa, h, &st);
                             } else {
                                 primAnyOrder<COUNT>(sv, ref, r, aa, h, bad, &st);
                             }
-                            hT = h.t;
-                            hRef = h.ref;
                             if (bad) {
                                 retraceInReferenceOrder();
                             } else if (ref & kRefLast) {
@@ -894,7 +874,7 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
                     const int first = (int)fbits(n1.w);
                     const bool nobox = (w3 & kNoBox) != 0;
                     if (COUNT && !nobox) st.v[C_NODE]++;
-                    const bool pass = slabPass(n0, n1, r, invx, invy, invz, hT) || nobox;
+                    const bool pass = slabPass(n0, n1, r, invx, invy, invz, h.t) || nobox;
                     idx = pass ? idx + 1 : (int)(w3 & kSkipMask);
                     if (pass && first >= 0) {
                         p = first;
@@ -906,15 +886,13 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
             } while (popc64(__ballot(op == OP_REFBOX)) >= keep && keep > 0);
         } else if (chosen == OP_SHADE) {
             if (op == OP_SHADE) {
-                Hit h{hT, hRef, 0.f, 0.f};
-                if (hRef == kNoHit) {
+                if (h.ref == kNoHit) {
                     if (COUNT) st.v[C_MISS]++;
                     endPath(V3{sc.bg[0], sc.bg[1], sc.bg[2]});
                 } else if (mode == 0 && !guardsPass<COUNT>(sv, r, invx, invy, invz, h, &st)) {
                     retraceInReferenceOrder();
                 } else {
                     if (COUNT) st.v[C_HITS]++;
-                    if (hRef & kRefTri) triangleBarycentrics(sv, hRef & kRefId, r, h.bu, h.bv);
                     Surface sf = surfaceAt(sc, sv, r, h);
                     Ray out;
                     V3 atten, emit;
