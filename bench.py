@@ -60,6 +60,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--spp", type=int, default=SPP, help="samples per pixel per GPU per step")
+    ap.add_argument("--check", action="store_true",
+                    help="after timing, rank 0 renders the whole frame alone and compares it bit for bit with the gathered one")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo: rehearsal of the multi-rank path on fewer GPUs than ranks (ranks share devices, "
+                         "the gather goes through host memory); not a measurement")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -69,11 +74,16 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device; the product path has no CPU fallback")
+    if args.backend == "gloo":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     rt = load_package()
     from rtiow_amd import scenes, tiling
@@ -90,7 +100,7 @@ def main():
 
     n4 = tiling.payload_float4s(W, H, world)
     payload = torch.zeros(n4, 4, dtype=torch.float32, device=dev)
-    gathered = torch.zeros(world, n4, 4, dtype=torch.float32, device=dev) if world > 1 else None
+    gathered = torch.zeros(world * n4, 4, dtype=torch.float32, device=dev) if world > 1 else None  # rank payloads end to end
     frame = torch.zeros(H, W, 4, dtype=torch.float32, device=dev) if world > 1 else None
     ctx.set_target(W, H, rank, world, external_ptr=payload.data_ptr())
     spp_step = args.spp * world  # per-GPU work fixed: 1/world of the tiles, world x the samples
@@ -102,7 +112,12 @@ def main():
         if record:
             kernel_ms.append(ctx.last_render_ms())
         if world > 1:
-            dist.all_gather_into_tensor(gathered, payload)
+            if args.backend == "nccl":
+                dist.all_gather_into_tensor(gathered, payload)
+            else:
+                host = torch.empty(gathered.shape, dtype=gathered.dtype)
+                dist.all_gather_into_tensor(host, payload.cpu())
+                gathered.copy_(host)
             ctx.resolve_gathered(gathered.data_ptr(), world, frame.data_ptr())
 
     def fence():
@@ -110,6 +125,11 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
+
+    def max_over_ranks(x):
+        t = torch.tensor([x], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
     for _ in range(args.warmup):
         step(False)
@@ -120,9 +140,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = max_over_ranks(elapsed)
 
     # Kernel duration by HIP events on the launch stream, in separate untimed steps (reading an
     # event blocks the host, which must not sit inside the timed region).
@@ -151,10 +169,27 @@ def main():
             "workload": f"Book-1 cover scene (488 spheres, BVH(world)), {W}x{H}, {args.spp} spp per GPU per step "
                         f"({spp_step} spp frame), max depth 50, progressive accumulation",
             "samples_per_step": samples_per_step,
-            "parallelism": f"tiles8x8 sharded over {world} rank(s)" + (", all-gather (RCCL)" if world > 1 else ""),
+            "parallelism": f"tiles8x8 sharded over {world} rank(s)" + ((", all-gather (RCCL)" if args.backend == "nccl" else ", all-gather (gloo rehearsal through host memory)") if world > 1 else ""),
             "ms_per_64spp_frame": round(1e3 * elapsed / args.steps * 64.0 / spp_step, 4),
         },
     }
+
+    if args.check and world > 1:
+        fence()
+        if rank == 0:
+            solo = rt.Context(local_rank)
+            solo.upload_scene(scene)
+            solo.set_target(W, H)
+            solo.render(0, spp_step, MAX_DEPTH)
+            solo.sync()
+            want = solo.read_accum()
+            solo.close()
+            got = frame.cpu().numpy()
+            same = bool(np.array_equal(got[..., :3].view(np.uint32), want[..., :3].view(np.uint32)))
+            out["gathered_frame_equals_single_rank_render"] = same
+            if not same:
+                raise SystemExit("gathered frame differs from the single-rank render")
+        fence()
 
     if rank == 0:
         # Algorithmic flops per launch from the kernel's own path statistics (a counting launch
