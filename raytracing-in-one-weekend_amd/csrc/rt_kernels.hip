@@ -767,8 +767,13 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
     auto endPath = [&](V3 terminal) {
         const V3 c = thr * terminal;
         a.colors[unit] = make_float4(c.x, c.y, c.z, 0.f);
+        depth = 0;  // nothing left to finish (see afterWalk)
         op = OP_NEWPATH;
     };
+    // Where a lane goes when its walk is over.  A ray that hit nothing needs no shading: the lane
+    // goes straight on to NEWPATH, which first writes throughput x background for the path it
+    // still holds (depth > 0 marks that), so SHADE executions carry hits only.
+    auto afterWalk = [&]() { return h.ref == kNoHit ? OP_NEWPATH : OP_SHADE; };
 
     for (;;) {
         const int cBox = popc64(__ballot(op == OP_BOX)), cPrim = popc64(__ballot(op == OP_PRIM)),
@@ -820,7 +825,7 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
                             const bool leaf = pass && first >= 0;
                             idx = pass ? idx + 1 : (int)fbits(n1.z);
                             p = leaf ? first : p;
-                            op = leaf ? OP_PRIM : (idx >= nNodesFast ? OP_SHADE : OP_BOX);
+                            op = leaf ? OP_PRIM : (idx >= nNodesFast ? afterWalk() : OP_BOX);
                         }
                     };
                     do {  // three steps per look at the lane count (1: 32.35 ms, 2: 31.75, 3: 31.6, 4: 31.7)
@@ -842,7 +847,7 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
                             if (bad) {
                                 retraceInReferenceOrder();
                             } else if (ref & kRefLast) {
-                                op = idx >= (mode ? nNodesRef : nNodesFast) ? OP_SHADE : (mode ? OP_REFBOX : OP_BOX);
+                                op = idx >= (mode ? nNodesRef : nNodesFast) ? afterWalk() : (mode ? OP_REFBOX : OP_BOX);
                             } else {
                                 p += 1;
                             }
@@ -880,16 +885,13 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
                         p = first;
                         op = OP_PRIM;
                     } else if (idx >= nNodesRef) {
-                        op = OP_SHADE;
+                        op = afterWalk();
                     }
                 }
             } while (popc64(__ballot(op == OP_REFBOX)) >= keep && keep > 0);
         } else if (chosen == OP_SHADE) {
             if (op == OP_SHADE) {
-                if (h.ref == kNoHit) {
-                    if (COUNT) st.v[C_MISS]++;
-                    endPath(V3{sc.bg[0], sc.bg[1], sc.bg[2]});
-                } else if (mode == 0 && !guardsPass<COUNT>(sv, r, invx, invy, invz, h, &st)) {
+                if (mode == 0 && !guardsPass<COUNT>(sv, r, invx, invy, invz, h, &st)) {
                     retraceInReferenceOrder();
                 } else {
                     if (COUNT) st.v[C_HITS]++;
@@ -913,6 +915,10 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
             }
         } else {  // OP_NEWPATH: the next unit for every waiting lane, in lane order, and its camera ray
             const bool want = op == OP_NEWPATH;
+            if (want && depth > 0) {  // the path this lane holds ended on the background
+                if (COUNT) st.v[C_MISS]++;
+                endPath(V3{sc.bg[0], sc.bg[1], sc.bg[2]});
+            }
             const unsigned long long m = __ballot(want);
             if (chunk >= 0 && chunkNext >= 64) {  // chunk used up: take the next one from the queue
                 unsigned int c = 0;
