@@ -59,7 +59,7 @@ struct Builder {
     std::vector<PrimBox>& prims;
     std::vector<uint32_t>& nodes;
     std::vector<uint32_t>& refs;
-    static constexpr int kBins = 16;
+    static constexpr int kBins = 64;
     int kMaxLeaf = 2;
 
     int newEntry(const float* mn, const float* mx) {
