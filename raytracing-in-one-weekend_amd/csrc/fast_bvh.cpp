@@ -61,6 +61,7 @@ struct Builder {
     std::vector<uint32_t>& refs;
     static constexpr int kBins = 64;
     int kMaxLeaf = 2;
+    int order = 2;  // 1: child with the smaller box first, 2: larger first, 0: as partitioned
 
     int newEntry(const float* mn, const float* mx) {
         int idx = (int)(nodes.size() / 8);
@@ -164,8 +165,9 @@ struct Builder {
             for (size_t i = start; i < end; i++) refs.push_back(prims[i].ref);
             refs.back() |= kRefLast;
         } else {
-            // the child with the smaller box first: the big one (e.g. the ground) is then tested
-            // with a closest hit already in hand more often
+            // the child with the larger box first: it is the likelier one to hold the closest hit, and a
+            // hit in hand lets the walk cull the rest sooner (cover scene 29.2 ms; smaller first 29.8, as
+            // partitioned 30.7)
             auto rangeArea = [&](size_t a, size_t b) {
                 float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
                 for (size_t i = a; i < b; i++)
@@ -175,7 +177,8 @@ struct Builder {
                     }
                 return area(lo, hi);
             };
-            if (rangeArea(start, mid) > rangeArea(mid, end)) {
+            const float aL = rangeArea(start, mid), aR = rangeArea(mid, end);
+            if (order == 1 ? aL > aR : (order == 2 ? aL < aR : false)) {
                 std::rotate(prims.begin() + start, prims.begin() + mid, prims.begin() + end);
                 mid = start + (end - mid);
             }
@@ -294,6 +297,7 @@ void Scene::buildFastStructure() {
     }
     Builder bld{prims, f.fast_nodes, f.fast_refs};
     if (const char* e = std::getenv("RT_FAST_LEAF")) bld.kMaxLeaf = std::max(1, std::atoi(e));
+    if (const char* e = std::getenv("RT_FAST_ORDER")) bld.order = std::atoi(e);
     bld.build(0, prims.size());
 }
 
