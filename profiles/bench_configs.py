@@ -2,12 +2,14 @@
 
   C1  cover scene 1200x675, 10 spp                      (the reference's CPU-runnable case)
   C3  Cornell box + brass vase (glTF fixture, 2,760 triangles), three synthetic 4096^2 maps, 1080p 256 spp
-  C5s instanced vases on a jittered grid, N triangles (default 1e6), 1080p, unlimited-depth reference BVH
+  C4  cover scene 3840x2160, 1024 spp
+  C5s instanced vases on a jittered grid, N triangles (default 1e6), 1080p 16 spp, unlimited-depth reference BVH
+  C5  the same scene at 3840x2160, 256 spp
 
 Each case: upload, one timed launch (HIP events), path counters, and a bit-exact spot check of a few
 image rows against the CPU oracle.  Prints one JSON line per case.
 
-Usage: python profiles/bench_configs.py [c1] [c3] [c5s[:triangles]]
+Usage: python profiles/bench_configs.py [c1] [c3] [c4] [c5s[:triangles]] [c5[:triangles]]
 """
 import json
 import os
@@ -85,7 +87,11 @@ def c3():
         1920, 1080, 256, [100, 540, 900], oracle_spp=4)
 
 
-def c5s(n_tris):
+def c4():
+    run("C4 cover 3840x2160x1024", lambda s: scenes.cover_scene(s, 3840, 2160), 3840, 2160, 1024, [1080], oracle_spp=2)
+
+
+def c5s(n_tris, w=1920, h=1080, spp=16):
     mesh = scenes.load_gltf_mesh(G)
     per = mesh["indices"].shape[0]
     copies = max(1, n_tris // per)
@@ -113,7 +119,7 @@ def c5s(n_tris):
         s.set_camera((278.0, 400.0, -800.0), (278.0, 150.0, 300.0), (0.0, 1.0, 0.0), 40.0, 1.0, 0.0, 10.0)
         s.set_background((0.6, 0.7, 0.9))
 
-    run(f"C5s {copies} vases = {copies * per} triangles, 1080p x16", build, 1920, 1080, 16, [540], oracle_spp=1)
+    run(f"C5 {copies} vases = {copies * per} triangles, {w}x{h}x{spp}", build, w, h, spp, [h // 2], oracle_spp=1)
 
 
 def heartbeat():
@@ -135,5 +141,9 @@ if __name__ == "__main__":
             c1()
         elif a == "c3":
             c3()
+        elif a == "c4":
+            c4()
         elif a.startswith("c5s"):
             c5s(int(float(a.split(":")[1])) if ":" in a else 1_000_000)
+        elif a.startswith("c5"):
+            c5s(int(float(a.split(":")[1])) if ":" in a else 10_000_000, 3840, 2160, 256)
