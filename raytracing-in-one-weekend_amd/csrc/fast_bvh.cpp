@@ -55,13 +55,31 @@ inline float area(const float* mn, const float* mx) {
     return 2.0f * (dx * dy + dy * dz + dz * dx);
 }
 
+// Two phases: a binary tree by the binned surface-area heuristic, then its emission in walk order
+// (entry, then its children; `skip` = the entry after the subtree).  The walk needs no binary shape,
+// so the emission may leave an inner entry out and hand its children to the entry above.
 struct Builder {
     std::vector<PrimBox>& prims;
     std::vector<uint32_t>& nodes;
     std::vector<uint32_t>& refs;
     static constexpr int kBins = 64;
     int kMaxLeaf = 2;
-    int order = 2;  // 1: child with the smaller box first, 2: larger first, 0: as partitioned
+    // An inner entry is left out when its box has more than this share of the area of the entry above:
+    // its test would pass for most rays that get there, and costs more than it saves (0 keeps all).
+    // Cover scene 29.2 -> 28.6 ms, Cornell + vase 336 -> 301 ms, 1 M triangles 73 -> 69 ms at 0.5.
+    float collapse = 0.5f;
+    // children of one entry in descending box area: the larger box is the likelier one to hold the
+    // closest hit, and a hit in hand lets the walk cull the rest sooner (cover scene: larger first
+    // 29.2 ms, smaller first 29.8, as partitioned 30.7)
+    int order = 2;  // of each pair: 1 smaller first, 2 larger first, 0 as partitioned; 3: all children of an entry by descending area
+
+    struct TNode {
+        float mn[3], mx[3];
+        float area;
+        int left, right;  // -1: leaf over prims[start, end)
+        size_t start, end;
+    };
+    std::vector<TNode> tree;
 
     int newEntry(const float* mn, const float* mx) {
         int idx = (int)(nodes.size() / 8);
@@ -72,7 +90,7 @@ struct Builder {
         return idx;
     }
 
-    void build(size_t start, size_t end) {
+    int build(size_t start, size_t end) {
         float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
         float cmn[3] = {INFINITY, INFINITY, INFINITY}, cmx[3] = {-INFINITY, -INFINITY, -INFINITY};
         for (size_t i = start; i < end; i++) {
@@ -84,108 +102,143 @@ struct Builder {
                 cmx[k] = std::max(cmx[k], c);
             }
         }
-        const int e = newEntry(mn, mx);
+        const int t = (int)tree.size();
+        tree.push_back(TNode{{mn[0], mn[1], mn[2]}, {mx[0], mx[1], mx[2]}, area(mn, mx), -1, -1, start, end});
         const size_t n = end - start;
+        if (n <= (size_t)kMaxLeaf) return t;
         size_t mid = 0;
-        bool split = n > (size_t)kMaxLeaf;
-        if (split) {
-            // binned surface-area heuristic over the centroid bounds
-            float bestCost = INFINITY;
-            int bestAxis = -1, bestBin = -1;
-            for (int ax = 0; ax < 3; ax++) {
-                const float ext = cmx[ax] - cmn[ax];
-                if (!(ext > 0)) continue;
-                float bmn[kBins][3], bmx[kBins][3];
-                int cnt[kBins] = {0};
-                for (int b = 0; b < kBins; b++)
-                    for (int k = 0; k < 3; k++) {
-                        bmn[b][k] = INFINITY;
-                        bmx[b][k] = -INFINITY;
-                    }
-                const float scale = kBins / ext;
-                for (size_t i = start; i < end; i++) {
-                    float c = 0.5f * (prims[i].mn[ax] + prims[i].mx[ax]);
-                    int b = std::min(kBins - 1, std::max(0, (int)((c - cmn[ax]) * scale)));
-                    cnt[b]++;
-                    for (int k = 0; k < 3; k++) {
-                        bmn[b][k] = std::min(bmn[b][k], prims[i].mn[k]);
-                        bmx[b][k] = std::max(bmx[b][k], prims[i].mx[k]);
-                    }
-                }
-                float rArea[kBins];
-                int rCnt[kBins];
-                float amn[3] = {INFINITY, INFINITY, INFINITY}, amx[3] = {-INFINITY, -INFINITY, -INFINITY};
-                int c = 0;
-                for (int b = kBins - 1; b > 0; b--) {
-                    for (int k = 0; k < 3; k++) {
-                        amn[k] = std::min(amn[k], bmn[b][k]);
-                        amx[k] = std::max(amx[k], bmx[b][k]);
-                    }
-                    c += cnt[b];
-                    rArea[b] = c ? area(amn, amx) : 0.0f;
-                    rCnt[b] = c;
-                }
+        // binned surface-area heuristic over the centroid bounds
+        float bestCost = INFINITY;
+        int bestAxis = -1, bestBin = -1;
+        for (int ax = 0; ax < 3; ax++) {
+            const float ext = cmx[ax] - cmn[ax];
+            if (!(ext > 0)) continue;
+            float bmn[kBins][3], bmx[kBins][3];
+            int cnt[kBins] = {0};
+            for (int b = 0; b < kBins; b++)
                 for (int k = 0; k < 3; k++) {
-                    amn[k] = INFINITY;
-                    amx[k] = -INFINITY;
+                    bmn[b][k] = INFINITY;
+                    bmx[b][k] = -INFINITY;
                 }
-                c = 0;
-                for (int b = 0; b < kBins - 1; b++) {
-                    for (int k = 0; k < 3; k++) {
-                        amn[k] = std::min(amn[k], bmn[b][k]);
-                        amx[k] = std::max(amx[k], bmx[b][k]);
-                    }
-                    c += cnt[b];
-                    if (c == 0 || rCnt[b + 1] == 0) continue;
-                    float cost = area(amn, amx) * c + rArea[b + 1] * rCnt[b + 1];
-                    if (cost < bestCost) {
-                        bestCost = cost;
-                        bestAxis = ax;
-                        bestBin = b;
-                    }
+            const float scale = kBins / ext;
+            for (size_t i = start; i < end; i++) {
+                float c = 0.5f * (prims[i].mn[ax] + prims[i].mx[ax]);
+                int b = std::min(kBins - 1, std::max(0, (int)((c - cmn[ax]) * scale)));
+                cnt[b]++;
+                for (int k = 0; k < 3; k++) {
+                    bmn[b][k] = std::min(bmn[b][k], prims[i].mn[k]);
+                    bmx[b][k] = std::max(bmx[b][k], prims[i].mx[k]);
                 }
             }
-            if (bestAxis < 0) {
-                // all centroids coincide: split by count
-                mid = start + n / 2;
-            } else {
-                const float ext = cmx[bestAxis] - cmn[bestAxis];
-                const float scale = kBins / ext;
-                auto it = std::partition(prims.begin() + start, prims.begin() + end, [&](const PrimBox& p) {
-                    float c = 0.5f * (p.mn[bestAxis] + p.mx[bestAxis]);
-                    int b = std::min(kBins - 1, std::max(0, (int)((c - cmn[bestAxis]) * scale)));
-                    return b <= bestBin;
-                });
-                mid = (size_t)(it - prims.begin());
-                if (mid == start || mid == end) mid = start + n / 2;
+            float rArea[kBins];
+            int rCnt[kBins];
+            float amn[3] = {INFINITY, INFINITY, INFINITY}, amx[3] = {-INFINITY, -INFINITY, -INFINITY};
+            int c = 0;
+            for (int b = kBins - 1; b > 0; b--) {
+                for (int k = 0; k < 3; k++) {
+                    amn[k] = std::min(amn[k], bmn[b][k]);
+                    amx[k] = std::max(amx[k], bmx[b][k]);
+                }
+                c += cnt[b];
+                rArea[b] = c ? area(amn, amx) : 0.0f;
+                rCnt[b] = c;
+            }
+            for (int k = 0; k < 3; k++) {
+                amn[k] = INFINITY;
+                amx[k] = -INFINITY;
+            }
+            c = 0;
+            for (int b = 0; b < kBins - 1; b++) {
+                for (int k = 0; k < 3; k++) {
+                    amn[k] = std::min(amn[k], bmn[b][k]);
+                    amx[k] = std::max(amx[k], bmx[b][k]);
+                }
+                c += cnt[b];
+                if (c == 0 || rCnt[b + 1] == 0) continue;
+                float cost = area(amn, amx) * c + rArea[b + 1] * rCnt[b + 1];
+                if (cost < bestCost) {
+                    bestCost = cost;
+                    bestAxis = ax;
+                    bestBin = b;
+                }
             }
         }
-        if (!split) {
+        if (bestAxis < 0) {
+            // all centroids coincide: split by count
+            mid = start + n / 2;
+        } else {
+            const float ext = cmx[bestAxis] - cmn[bestAxis];
+            const float scale = kBins / ext;
+            auto it = std::partition(prims.begin() + start, prims.begin() + end, [&](const PrimBox& p) {
+                float c = 0.5f * (p.mn[bestAxis] + p.mx[bestAxis]);
+                int b = std::min(kBins - 1, std::max(0, (int)((c - cmn[bestAxis]) * scale)));
+                return b <= bestBin;
+            });
+            mid = (size_t)(it - prims.begin());
+            if (mid == start || mid == end) mid = start + n / 2;
+        }
+        const int l = build(start, mid);
+        const int r = build(mid, end);
+        tree[t].left = l;
+        tree[t].right = r;
+        return t;
+    }
+
+    // the two children of a tree node in visiting order
+    void pairOf(const TNode& n, int& first, int& second) const {
+        first = n.left;
+        second = n.right;
+        const float aL = tree[n.left].area, aR = tree[n.right].area;
+        if (order == 1 ? aL > aR : (order >= 2 ? aL < aR : false)) std::swap(first, second);
+    }
+
+    // the entries that stand directly below a kept entry of area `above`: a child is either kept
+    // or replaced, in place, by its own children
+    void gather(int t, float above, std::vector<int>& out) const {
+        const TNode& n = tree[t];
+        if (n.left >= 0 && collapse > 0.0f && n.area > collapse * above) {
+            int a, b;
+            pairOf(n, a, b);
+            gather(a, above, out);
+            gather(b, above, out);
+        } else {
+            out.push_back(t);
+        }
+    }
+
+    void emitChildren(int t, float above) {
+        std::vector<int> kids;
+        int a, b;
+        pairOf(tree[t], a, b);
+        gather(a, above, kids);
+        gather(b, above, kids);
+        emitList(kids);
+    }
+
+    void emitList(std::vector<int>& list) {
+        if (order == 3)
+            std::stable_sort(list.begin(), list.end(), [&](int a, int b) { return tree[a].area > tree[b].area; });
+        for (int t : list) emit(t);
+    }
+
+    void emit(int t) {
+        const TNode n = tree[t];
+        const int e = newEntry(n.mn, n.mx);
+        if (n.left < 0) {
             nodes[(size_t)e * 8 + 7] = (uint32_t)refs.size();
-            for (size_t i = start; i < end; i++) refs.push_back(prims[i].ref);
+            for (size_t i = n.start; i < n.end; i++) refs.push_back(prims[i].ref);
             refs.back() |= kRefLast;
         } else {
-            // the child with the larger box first: it is the likelier one to hold the closest hit, and a
-            // hit in hand lets the walk cull the rest sooner (cover scene 29.2 ms; smaller first 29.8, as
-            // partitioned 30.7)
-            auto rangeArea = [&](size_t a, size_t b) {
-                float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-                for (size_t i = a; i < b; i++)
-                    for (int k = 0; k < 3; k++) {
-                        lo[k] = std::min(lo[k], prims[i].mn[k]);
-                        hi[k] = std::max(hi[k], prims[i].mx[k]);
-                    }
-                return area(lo, hi);
-            };
-            const float aL = rangeArea(start, mid), aR = rangeArea(mid, end);
-            if (order == 1 ? aL > aR : (order == 2 ? aL < aR : false)) {
-                std::rotate(prims.begin() + start, prims.begin() + mid, prims.begin() + end);
-                mid = start + (end - mid);
-            }
-            build(start, mid);
-            build(mid, end);
+            emitChildren(t, n.area);
         }
         nodes[(size_t)e * 8 + 6] = (uint32_t)(nodes.size() / 8);
+    }
+
+    void run() {
+        const int root = build(0, prims.size());
+        std::vector<int> top;
+        gather(root, tree[root].area, top);  // the root itself goes when it is an inner entry
+        emitList(top);
     }
 };
 
@@ -298,7 +351,8 @@ void Scene::buildFastStructure() {
     Builder bld{prims, f.fast_nodes, f.fast_refs};
     if (const char* e = std::getenv("RT_FAST_LEAF")) bld.kMaxLeaf = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("RT_FAST_ORDER")) bld.order = std::atoi(e);
-    bld.build(0, prims.size());
+    if (const char* e = std::getenv("RT_FAST_COLLAPSE")) bld.collapse = (float)std::atof(e);
+    bld.run();
 }
 
 }  // namespace rt
