@@ -136,6 +136,14 @@ int rt_scene_get_flat(const rt_scene* s, uint32_t* nodes8, uint32_t* prim_refs, 
                       float* tri_pos9, float* tri_normal9, float* tri_uv6, int32_t* tri_mat, int32_t* mat_kind,
                       float* mat_rgbp4);
 
+/* The structure the kernels search first (no counterpart in the reference: a tighter tree over
+ * the same primitives whose answer is checked against the reference's boxes, see rt_render).
+ * entries: 8 x 32-bit words {min.x, max.x, min.y, max.y, min.z, max.z, skip, first_ref}, in walk
+ * order (an entry whose box passes is followed by entry + 1, one whose box fails by `skip`);
+ * first_ref = 0xFFFFFFFF for an entry without a leaf run.  refs: as prim_refs.  Sizes come back in
+ * n_entries / n_refs; either array may be NULL (call once for the sizes, once for the data). */
+int rt_scene_get_search_structure(const rt_scene* s, int* n_entries, uint32_t* entries8, int* n_refs, uint32_t* refs);
+
 /* ------------------------------------------------------------------ device */
 
 int rt_device_count(void);

@@ -69,6 +69,7 @@ SYMBOLS = {
     "rt_scene_set_background": (_I, [_VP, _F, _F, _F]),
     "rt_scene_flatten": (_I, [_VP, C.POINTER(FlatInfo)]),
     "rt_scene_get_flat": (_I, [_VP] + [_VP] * 10),
+    "rt_scene_get_search_structure": (_I, [_VP, C.POINTER(_I), _VP, C.POINTER(_I), _VP]),
     "rt_device_count": (_I, []),
     "rt_create": (_I, [_I, C.POINTER(_VP)]),
     "rt_destroy": (None, [_VP]),
@@ -235,6 +236,16 @@ class Scene:
             "mat_rgbp")]))
         d["info"] = info
         return d
+
+    def search_structure(self):
+        """The flattened scene's search structure: (entries [n, 8] uint32, refs [m] uint32)."""
+        self.flatten()
+        ne, nr = C.c_int(0), C.c_int(0)
+        _check(lib.rt_scene_get_search_structure(self.h, C.byref(ne), None, C.byref(nr), None))
+        entries = np.zeros((ne.value, 8), np.uint32)
+        refs = np.zeros(nr.value, np.uint32)
+        _check(lib.rt_scene_get_search_structure(self.h, None, _p(entries), None, _p(refs)))
+        return entries, refs
 
 
 def device_count():

@@ -354,6 +354,17 @@ int rt_scene_get_flat(const rt_scene* s, uint32_t* nodes8, uint32_t* prim_refs, 
     return RT_OK;
 }
 
+int rt_scene_get_search_structure(const rt_scene* s, int* n_entries, uint32_t* entries8, int* n_refs, uint32_t* refs) {
+    if (!s) return fail(RT_ERR_INVALID, "null scene");
+    const rt::Scene& sc = s->sc;
+    if (!sc.flat.valid) return fail(RT_ERR_STATE, "rt_scene_flatten() has not been called");
+    if (n_entries) *n_entries = (int)(sc.flat.fast_nodes.size() / 8);
+    if (n_refs) *n_refs = (int)sc.flat.fast_refs.size();
+    if (entries8) std::memcpy(entries8, sc.flat.fast_nodes.data(), sc.flat.fast_nodes.size() * 4);
+    if (refs) std::memcpy(refs, sc.flat.fast_refs.data(), sc.flat.fast_refs.size() * 4);
+    return RT_OK;
+}
+
 // ------------------------------------------------------------------ device
 int rt_device_count(void) {
     int n = 0;

@@ -1,0 +1,145 @@
+"""Invariants of the structure the kernels search first (host side, no GPU).
+
+The kernels' answer is only kept when the reference's own boxes confirm it, so a wrong search
+structure cannot change an image -- but it could silently cull a closest hit often enough to
+send every ray through the slow reference-order walk, or loop.  These tests pin what the walk
+relies on: links only point forward, subtrees nest, every primitive of the world is listed exactly
+once, and every entry's box encloses the true bounds of everything listed below it.
+"""
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+G = os.path.join(HERE, "golden")
+LAST, TRI = 1 << 31, 1 << 30
+NONE = 0xFFFFFFFF
+
+
+def prim_bounds(flat, ref):
+    i = int(ref & (TRI - 1))
+    if ref & TRI:
+        p = flat["tri_pos"][i].reshape(3, 3)
+        return p.min(axis=0), p.max(axis=0)
+    c, r = flat["spheres"][i, :3], abs(flat["spheres"][i, 3])
+    return c - r, c + r
+
+
+def check_search_structure(scene):
+    flat = scene.get_flat()
+    entries, refs = scene.search_structure()
+    n = len(entries)
+    assert n >= 1
+    box = entries[:, :6].view(np.float32)
+    skip = entries[:, 6].astype(np.int64)
+    first = entries[:, 7]
+
+    # forward links, nested subtrees
+    for e in range(n):
+        assert e < skip[e] <= n
+    stack = []
+    for e in range(n):
+        while stack and stack[-1] <= e:
+            stack.pop()
+        if stack:
+            assert skip[e] <= stack[-1], "a subtree reaches past the subtree that holds it"
+        stack.append(skip[e])
+
+    # leaf runs: terminated, in array order, covering refs exactly; leaves have no entries below
+    pos = 0
+    runs = {}
+    for e in range(n):
+        if first[e] != NONE:
+            assert first[e] == pos
+            assert skip[e] == e + 1, "an entry with a leaf run has no entries below it"
+            start = pos
+            while not (refs[pos] & LAST):
+                pos += 1
+            pos += 1
+            runs[e] = (start, pos)
+        else:
+            assert skip[e] > e + 1, "an inner entry without anything below it"
+    assert pos == len(refs)
+
+    # every primitive of the world exactly once
+    world = np.unique(flat["prim_refs"] & ~np.uint32(LAST))
+    listed = refs & ~np.uint32(LAST)
+    assert len(listed) == len(world) and np.array_equal(np.sort(listed), world)
+
+    # boxes enclose the true bounds of everything below them
+    lo = np.full((n, 3), np.inf, np.float32)
+    hi = np.full((n, 3), -np.inf, np.float32)
+    for e, (a, b) in runs.items():
+        for r in refs[a:b]:
+            mn, mx = prim_bounds(flat, r)
+            lo[e] = np.minimum(lo[e], mn)
+            hi[e] = np.maximum(hi[e], mx)
+    for e in range(n - 1, -1, -1):   # fold every entry into the entries that hold it
+        j = e + 1
+        while j < skip[e]:
+            lo[e] = np.minimum(lo[e], lo[j])
+            hi[e] = np.maximum(hi[e], hi[j])
+            j = skip[j]
+    assert (box[:, 0::2] <= lo).all() and (box[:, 1::2] >= hi).all()
+    return entries, refs
+
+
+@pytest.mark.parametrize("wrap", [False, True])
+def test_cover_scene(rt, scenes, wrap):
+    s = rt.Scene()
+    scenes.cover_scene(s, 640, 360, wrap_bvh=wrap)
+    entries, refs = check_search_structure(s)
+    assert len(refs) == 488
+    # the structure does not depend on how the reference's own BVH was built
+    t = rt.Scene()
+    scenes.cover_scene(t, 640, 360, wrap_bvh=not wrap)
+    e2, r2 = t.search_structure()
+    assert np.array_equal(entries, e2) and np.array_equal(refs & ~np.uint32(LAST), r2 & ~np.uint32(LAST))
+
+
+def test_cornell_and_vase(rt, scenes):
+    mesh = scenes.load_gltf_mesh(os.path.join(G, "brass_vase", "brass_vase_04_4k.gltf"))
+    tex = {"diffuse": scenes.noise_texture(16, 1), "roughness": scenes.noise_texture(16, 2), "normal": None}
+    s = rt.Scene()
+    scenes.cornell_mesh_scene(s, 640, 360, mesh, tex)
+    _, refs = check_search_structure(s)
+    assert len(refs) == 12 + 2760
+
+
+def test_mixed_world(rt, scenes):
+    mesh = scenes.lathe_mesh(6, 4, seed=9)
+    s = rt.Scene()
+    m = [s.add_material(0, (0.5, 0.4, 0.3)), s.add_material(1, (0.9, 0.8, 0.7), 0.2)]
+    rr = np.random.RandomState(5)
+    for i in range(40):
+        c = (rr.rand(3) * 400 + 50).astype(np.float32)
+        s.add_sphere(c, float(np.float32(5 + 20 * rr.rand())), m[i % 2])
+    for i in range(9):
+        s.add_triangle((rr.rand(9) * 500).astype(np.float32), m[i % 2])
+    td = s.add_texture(scenes.noise_texture(8, 1))
+    s.add_mesh(scenes.VASE_MODEL, mesh["positions"], mesh["indices"], s.add_pbr(td, -1, -1),
+               normals=mesh["normals"], uvs=mesh["uvs"], max_depth=2)
+    s.wrap_bvh()
+    check_search_structure(s)
+
+
+def test_coincident_and_single_primitives(rt):
+    """All centroids equal (the split falls back to halving the list), and a world of one."""
+    s = rt.Scene()
+    m = s.add_material(0, (0.5, 0.5, 0.5))
+    for _ in range(9):
+        s.add_sphere((1.0, 2.0, 3.0), 0.5, m)
+    check_search_structure(s)
+    one = rt.Scene()
+    one.add_sphere((0.0, 0.0, 0.0), 1.0, one.add_material(0, (1, 1, 1)))
+    entries, refs = check_search_structure(one)
+    assert len(entries) == 1 and len(refs) == 1
+
+
+def test_empty_world(rt):
+    s = rt.Scene()
+    entries, refs = s.search_structure()
+    assert len(entries) == 1 and len(refs) == 0
+    b = entries[0, :6].view(np.float32)
+    assert (b[0::2] > b[1::2]).all() and entries[0, 7] == NONE   # inverted box, no leaf run
