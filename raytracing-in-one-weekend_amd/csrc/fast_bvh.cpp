@@ -68,10 +68,13 @@ struct Builder {
     // its test would pass for most rays that get there, and costs more than it saves (0 keeps all).
     // Cover scene 29.2 -> 28.6 ms, Cornell + vase 336 -> 301 ms, 1 M triangles 73 -> 69 ms at 0.5.
     float collapse = 0.5f;
-    // children of one entry in descending box area: the larger box is the likelier one to hold the
-    // closest hit, and a hit in hand lets the walk cull the rest sooner (cover scene: larger first
-    // 29.2 ms, smaller first 29.8, as partitioned 30.7)
-    int order = 2;  // of each pair: 1 smaller first, 2 larger first, 0 as partitioned; 3: all children of an entry by descending area
+    // Which child of a pair is visited first.  A hit in hand lets the walk cull what comes after, so
+    // the likelier holder of the closest hit goes first: for camera rays that is the box nearer to the
+    // eye, for the rest the larger box.  Cover scene: as partitioned 30.7 ms, smaller first 29.8, larger
+    // first 29.2 (28.6 with `collapse`), nearer to the eye first (larger on a tie) 27.9.  A million
+    // triangles at 6.9 rays per sample lose 2 % with the eye rule, Cornell + vase is indifferent.
+    int order = 4;  // 0 as partitioned, 1 smaller first, 2 larger first, 3 all children of an entry by descending area, 4 nearer to the eye first
+    float eye[3] = {0, 0, 0};
 
     struct TNode {
         float mn[3], mx[3];
@@ -184,11 +187,25 @@ struct Builder {
         return t;
     }
 
+    float eyeDistance(const TNode& n) const {
+        float d2 = 0;
+        for (int k = 0; k < 3; k++) {
+            const float d = std::max(0.0f, std::max(n.mn[k] - eye[k], eye[k] - n.mx[k]));
+            d2 += d * d;
+        }
+        return d2;
+    }
+
     // the two children of a tree node in visiting order
     void pairOf(const TNode& n, int& first, int& second) const {
         first = n.left;
         second = n.right;
         const float aL = tree[n.left].area, aR = tree[n.right].area;
+        if (order == 4) {
+            const float dL = eyeDistance(tree[n.left]), dR = eyeDistance(tree[n.right]);
+            if (dL == dR ? aL < aR : dL > dR) std::swap(first, second);
+            return;
+        }
         if (order == 1 ? aL > aR : (order >= 2 ? aL < aR : false)) std::swap(first, second);
     }
 
@@ -246,6 +263,7 @@ struct Builder {
 
 void Scene::buildFastStructure() {
     FlatScene& f = flat;
+    f.fast_stale = false;
     f.fast_nodes.clear();
     f.fast_refs.clear();
     f.sphere_ord.assign(spheres.size(), -1);
@@ -352,6 +370,7 @@ void Scene::buildFastStructure() {
     if (const char* e = std::getenv("RT_FAST_LEAF")) bld.kMaxLeaf = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("RT_FAST_ORDER")) bld.order = std::atoi(e);
     if (const char* e = std::getenv("RT_FAST_COLLAPSE")) bld.collapse = (float)std::atof(e);
+    for (int k = 0; k < 3; k++) bld.eye[k] = camera.origin[k];
     bld.run();
 }
 

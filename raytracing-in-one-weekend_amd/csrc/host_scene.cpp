@@ -685,6 +685,10 @@ void Scene::setCamera(const float* lookfrom, const float* lookat, const float* v
     normalize3(c, u);
     cross3(w, u, v);
     float fw = focus * viewportWidth, fh = focus * viewportHeight;
+    // the search structure orders its entries by distance from the eye: a moved eye makes it stale
+    // (still correct, only slower), and the next flatten() rebuilds it
+    if (lookfrom[0] != camera.origin[0] || lookfrom[1] != camera.origin[1] || lookfrom[2] != camera.origin[2])
+        flat.fast_stale = true;
     for (int k = 0; k < 3; k++) {
         camera.origin[k] = lookfrom[k];
         camera.horizontal[k] = fw * u[k];
@@ -763,7 +767,10 @@ void Scene::emitComposite(const Composite& c) {
 }
 
 void Scene::flatten() {
-    if (flat.valid) return;
+    if (flat.valid) {
+        if (flat.fast_stale) buildFastStructure();
+        return;
+    }
     flat.nodes.clear();
     flat.prim_refs.clear();
     flat.max_leaf = 0;

@@ -58,6 +58,7 @@ struct FlatScene {
     std::vector<uint32_t> prim_refs;
     int max_leaf = 0;
     bool valid = false;
+    bool fast_stale = false;  // the search structure was ordered for another eye position
 
     // The search structure the kernels traverse first (fast_bvh.cpp): a SAH BVH over all
     // primitives with padded boxes, in the same threaded entry format.  Its answer is accepted

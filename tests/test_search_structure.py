@@ -143,3 +143,19 @@ def test_empty_world(rt):
     assert len(entries) == 1 and len(refs) == 0
     b = entries[0, :6].view(np.float32)
     assert (b[0::2] > b[1::2]).all() and entries[0, 7] == NONE   # inverted box, no leaf run
+
+
+def test_moved_eye_reorders_and_keeps_the_invariants(rt, scenes):
+    """Children are visited nearer-to-the-eye first, so the structure follows the camera: a new
+    eye position makes the next flatten rebuild it, the same position does not change it."""
+    s = rt.Scene()
+    scenes.cover_scene(s, 640, 360)
+    e0, r0 = check_search_structure(s)
+    cam = dict(lookat=(0.0, 0.0, 0.0), vup=(0.0, 1.0, 0.0), vfov=20.0, aspect=1.0, aperture=0.1, focus=10.0)
+    s.set_camera((13.0, 2.0, 3.0), cam["lookat"], cam["vup"], cam["vfov"], cam["aspect"], cam["aperture"], cam["focus"])
+    e1, r1 = s.search_structure()
+    assert np.array_equal(e0, e1) and np.array_equal(r0, r1)
+    s.set_camera((-13.0, 2.0, -3.0), cam["lookat"], cam["vup"], cam["vfov"], cam["aspect"], cam["aperture"], cam["focus"])
+    e2, r2 = check_search_structure(s)
+    assert e2.shape == e0.shape and not np.array_equal(e0, e2)
+    assert np.array_equal(np.sort(r0 & ~np.uint32(LAST)), np.sort(r2 & ~np.uint32(LAST)))
