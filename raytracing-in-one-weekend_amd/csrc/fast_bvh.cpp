@@ -64,7 +64,6 @@ struct Builder {
     std::vector<uint32_t>& refs;
     static constexpr int kBins = 64;
     int kMaxLeaf = 2;
-    int sweepMax = 0;  // ranges up to this length are split by the exact heuristic
     // An inner entry is left out when its box has more than this share of the area of the entry above:
     // its test would pass for most rays that get there, and costs more than it saves (0 keeps all).
     // Cover scene 29.2 -> 28.6 ms, Cornell + vase 336 -> 301 ms, 1 M triangles 73 -> 69 ms at 0.5.
@@ -94,10 +93,22 @@ struct Builder {
         return idx;
     }
 
-    // Binned surface-area heuristic over the centroid bounds; partitions prims[start, end) and
-    // returns the split position.
-    size_t binnedSplit(size_t start, size_t end, const float* cmn, const float* cmx) {
+    int build(size_t start, size_t end) {
+        float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+        float cmn[3] = {INFINITY, INFINITY, INFINITY}, cmx[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (size_t i = start; i < end; i++) {
+            for (int k = 0; k < 3; k++) {
+                mn[k] = std::min(mn[k], prims[i].mn[k]);
+                mx[k] = std::max(mx[k], prims[i].mx[k]);
+                float c = 0.5f * (prims[i].mn[k] + prims[i].mx[k]);
+                cmn[k] = std::min(cmn[k], c);
+                cmx[k] = std::max(cmx[k], c);
+            }
+        }
+        const int t = (int)tree.size();
+        tree.push_back(TNode{{mn[0], mn[1], mn[2]}, {mx[0], mx[1], mx[2]}, area(mn, mx), -1, -1, start, end});
         const size_t n = end - start;
+        if (n <= (size_t)kMaxLeaf) return t;
         size_t mid = 0;
         // binned surface-area heuristic over the centroid bounds
         float bestCost = INFINITY;
@@ -168,76 +179,6 @@ struct Builder {
             });
             mid = (size_t)(it - prims.begin());
             if (mid == start || mid == end) mid = start + n / 2;
-        }
-        return mid;
-    }
-
-    // Exact surface-area heuristic for short ranges: every split position of the centroid order on
-    // every axis.  Sorts prims[start, end) along the winning axis and returns the split position.
-    size_t sweepSplit(size_t start, size_t end) {
-        const size_t n = end - start;
-        float bestCost = INFINITY;
-        int bestAxis = -1;
-        size_t bestLeft = 0;
-        std::vector<float> rArea(n);
-        auto byCentroid = [&](int ax) {
-            std::stable_sort(prims.begin() + start, prims.begin() + end, [ax](const PrimBox& a, const PrimBox& b) {
-                return a.mn[ax] + a.mx[ax] < b.mn[ax] + b.mx[ax];
-            });
-        };
-        for (int ax = 0; ax < 3; ax++) {
-            byCentroid(ax);
-            float amn[3] = {INFINITY, INFINITY, INFINITY}, amx[3] = {-INFINITY, -INFINITY, -INFINITY};
-            for (size_t i = n; i-- > 1;) {
-                for (int k = 0; k < 3; k++) {
-                    amn[k] = std::min(amn[k], prims[start + i].mn[k]);
-                    amx[k] = std::max(amx[k], prims[start + i].mx[k]);
-                }
-                rArea[i] = area(amn, amx);
-            }
-            for (int k = 0; k < 3; k++) {
-                amn[k] = INFINITY;
-                amx[k] = -INFINITY;
-            }
-            for (size_t i = 0; i + 1 < n; i++) {
-                for (int k = 0; k < 3; k++) {
-                    amn[k] = std::min(amn[k], prims[start + i].mn[k]);
-                    amx[k] = std::max(amx[k], prims[start + i].mx[k]);
-                }
-                const float cost = area(amn, amx) * (float)(i + 1) + rArea[i + 1] * (float)(n - i - 1);
-                if (cost < bestCost) {
-                    bestCost = cost;
-                    bestAxis = ax;
-                    bestLeft = i + 1;
-                }
-            }
-        }
-        if (bestAxis < 0) return start + n / 2;
-        if (bestAxis != 2) byCentroid(bestAxis);
-        return start + bestLeft;
-    }
-
-    int build(size_t start, size_t end) {
-        float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-        float cmn[3] = {INFINITY, INFINITY, INFINITY}, cmx[3] = {-INFINITY, -INFINITY, -INFINITY};
-        for (size_t i = start; i < end; i++) {
-            for (int k = 0; k < 3; k++) {
-                mn[k] = std::min(mn[k], prims[i].mn[k]);
-                mx[k] = std::max(mx[k], prims[i].mx[k]);
-                float c = 0.5f * (prims[i].mn[k] + prims[i].mx[k]);
-                cmn[k] = std::min(cmn[k], c);
-                cmx[k] = std::max(cmx[k], c);
-            }
-        }
-        const int t = (int)tree.size();
-        tree.push_back(TNode{{mn[0], mn[1], mn[2]}, {mx[0], mx[1], mx[2]}, area(mn, mx), -1, -1, start, end});
-        const size_t n = end - start;
-        if (n <= (size_t)kMaxLeaf) return t;
-        size_t mid = 0;
-        if (n <= (size_t)sweepMax) {
-            mid = sweepSplit(start, end);
-        } else {
-            mid = binnedSplit(start, end, cmn, cmx);
         }
         const int l = build(start, mid);
         const int r = build(mid, end);
@@ -427,7 +368,6 @@ void Scene::buildFastStructure() {
     }
     Builder bld{prims, f.fast_nodes, f.fast_refs};
     if (const char* e = std::getenv("RT_FAST_LEAF")) bld.kMaxLeaf = std::max(1, std::atoi(e));
-    if (const char* e = std::getenv("RT_FAST_SWEEP")) bld.sweepMax = std::atoi(e);
     if (const char* e = std::getenv("RT_FAST_ORDER")) bld.order = std::atoi(e);
     if (const char* e = std::getenv("RT_FAST_COLLAPSE")) bld.collapse = (float)std::atof(e);
     for (int k = 0; k < 3; k++) bld.eye[k] = camera.origin[k];
