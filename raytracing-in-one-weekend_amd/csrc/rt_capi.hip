@@ -140,8 +140,8 @@ int checkRenderState(rt_context* ctx) {
     return RT_OK;
 }
 
-// Launch shape.  Default: the persistent wavefront loop, a fixed number of 256-thread
-// workgroups per CU that pull pixels from a queue.  RT_KERNEL=simple selects the plain
+// Launch shape.  Default: the persistent wavefront loop, three 512-thread workgroups per CU
+// whose waves pull chunks of 64 pixel samples from a queue.  RT_KERNEL=simple selects the plain
 // one-wave-per-tile kernel (kept for A/B measurements); both produce identical images.
 int launch(rt_context* ctx, rt::RenderArgs& a, bool count) {
     const int threads = 256;
@@ -160,7 +160,7 @@ int launch(rt_context* ctx, rt::RenderArgs& a, bool count) {
     a.knob[1] = envInt("RT_SHADE_MIN", 32);
     a.knob[3] = std::max(1, envInt("RT_PRIM_KEEP", 16));
     int wfThreads = envInt("RT_THREADS", 512);
-    if (wfThreads < 64 || wfThreads > 512 || wfThreads % 64 != 0) wfThreads = 512;
+    if (wfThreads < 64 || wfThreads > WF_MAX_THREADS || wfThreads % 64 != 0) wfThreads = 512;
     const int wfWaves = wfThreads / 64;
     // three 512-thread workgroups per CU = 6 waves per SIMD (two when the staged scene is too big)
     const int perCu = ctx->use_lds && ctx->lds_need > kLdsThreeGroups ? 2 : 3;

@@ -54,6 +54,11 @@ struct RenderArgs {
 
 constexpr int kTile = 8;  // one wave64 = one 8x8 pixel tile
 
+// largest workgroup the persistent kernel is compiled for (its launch bounds)
+#ifndef WF_MAX_THREADS
+#define WF_MAX_THREADS 512
+#endif
+
 // Bytes of LDS the staged scene tables need, each block 16-byte aligned (order = stageScene()).
 // with_reference_arrays = false leaves the reference-order entries, their leaf references and the
 // guard tables in global memory (they are touched once or twice per accepted hit and by the rare
