@@ -822,10 +822,10 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
                             const int first = (int)fbits(n1.w);
                             if (COUNT) st.v[C_NODE]++;
                             const bool pass = slabPassFast(n0, n1, invx, invy, invz, nox, noy, noz, h.t);
-                            const bool leaf = pass && first >= 0;
                             idx = pass ? idx + 1 : (int)fbits(n1.z);
-                            p = leaf ? first : p;
-                            op = leaf ? OP_PRIM : (idx >= nNodesFast ? afterWalk() : OP_BOX);
+                            p = first;  // read by PRIM only, which a lane enters with its leaf run's start
+                            const int onward = idx >= nNodesFast ? afterWalk() : OP_BOX;
+                            op = (pass & (first >= 0)) ? OP_PRIM : onward;
                         }
                     };
                     do {  // three steps per look at the lane count (1: 32.35 ms, 2: 31.75, 3: 31.6, 4: 31.7)
