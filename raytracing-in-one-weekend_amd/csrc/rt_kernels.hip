@@ -838,10 +838,23 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
                         if (op == OP_PRIM) {
                             const uint32_t ref = (mode ? sv.refs : sv.frefs)[p];
                             bool bad = false;
-                            if (mode) {
-                                primRef<COUNT>(sv, ref, r, aa, h, &st);
-                            } else {
-                                primAnyOrder<COUNT>(sv, ref, r, aa, h, bad, &st);
+                            // One copy of the primitive test for both walks (see primRef / primAnyOrder):
+                            // the reference-order walk tests against the running closest distance and takes
+                            // every hit; the search-structure walk tests without a limit and orders the hits.
+                            float t, u = mode ? h.bu : 0.0f, v = mode ? h.bv : 0.0f;
+                            if (primRoot<COUNT>(sv, ref, r, aa, mode ? h.t : __builtin_inff(), t, u, v, &st)) {
+                                bool take = true;
+                                if (!mode) {
+                                    bad = t != t;
+                                    take = !bad && (h.ref == kNoHit || t < h.t ||
+                                                    (t == h.t && refOrder(sv, ref) > refOrder(sv, h.ref)));
+                                }
+                                if (take) {
+                                    h.t = t;
+                                    h.ref = ref & ~kRefLast;
+                                    h.bu = u;
+                                    h.bv = v;
+                                }
                             }
                             if (bad) {
                                 retraceInReferenceOrder();
