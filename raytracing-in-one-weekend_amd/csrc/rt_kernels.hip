@@ -61,29 +61,6 @@ struct Rng {
     }
     // randomFloat(min, max), R/src/Core/RTWeekend.h:33-36
     __device__ __forceinline__ float next(float mn, float mx) { return mn + (mx - mn) * next(); }
-
-    __device__ __forceinline__ static float unitFloat(uint32_t m) {
-        return __uint_as_float((m & 0x007FFFFFu) | 0x3F800000u) - 1.0f;
-    }
-    // The next N draws at once: one look at the counter for all of them, so the common case (every
-    // counter inside the table) is N table reads and N hashes without a branch per draw.
-    template <int N>
-    __device__ __forceinline__ void nextN(float (&out)[N]) {
-        uint32_t inner[N];
-        if (counter + N < (uint32_t)kCounterLut) {
-#pragma unroll
-            for (int i = 0; i < N; i++) inner[i] = g_counterLut[counter + 1 + i];
-        } else {
-#pragma unroll
-            for (int i = 0; i < N; i++) {
-                const uint32_t c = counter + 1 + i;
-                inner[i] = c < (uint32_t)kCounterLut ? g_counterLut[c] : hashu(fbits((float)c));
-            }
-        }
-        counter += N;
-#pragma unroll
-        for (int i = 0; i < N; i++) out[i] = unitFloat(hashu(key ^ inner[i]));
-    }
 };
 
 struct V3 {
@@ -106,9 +83,7 @@ __device__ __forceinline__ V3 reflect(V3 I, V3 N) { return I - N * dot(N, I) * 2
 // randomVecInUnitSphere, R/src/Core/RTWeekend.cpp:3-12 (z, y, x draw order of the g++ build)
 __device__ __forceinline__ V3 randomInUnitSphere(Rng& rng) {
     for (;;) {
-        float u[3];
-        rng.nextN(u);
-        const float z = -1.0f + (1.0f - -1.0f) * u[0], y = -1.0f + (1.0f - -1.0f) * u[1], x = -1.0f + (1.0f - -1.0f) * u[2];
+        float z = rng.next(-1.0f, 1.0f), y = rng.next(-1.0f, 1.0f), x = rng.next(-1.0f, 1.0f);
         V3 p{x, y, z};
         if (dot(p, p) >= 1.0f) continue;
         return p;
@@ -532,10 +507,8 @@ __device__ __forceinline__ Ray cameraRay(const DevScene& sc, float s, float t, R
     const float* c = sc.cam;
     float px, py;
     for (;;) {
-        float u[2];
-        rng.nextN(u);
-        py = -1.0f + (1.0f - -1.0f) * u[0];
-        px = -1.0f + (1.0f - -1.0f) * u[1];
+        py = rng.next(-1.0f, 1.0f);
+        px = rng.next(-1.0f, 1.0f);
         if ((px * px + py * py) + 0.0f * 0.0f >= 1) continue;
         break;
     }
