@@ -701,7 +701,10 @@ __device__ __forceinline__ int popc64(unsigned long long m) {
 #ifndef WF_BOUNDS
 #define WF_BOUNDS 512, 6
 #endif
-template <bool LDS, bool COUNT>
+// TIME (diagnostic): instead of path counters, each wave adds up its clock ticks per operation
+// -- box bursts, primitive runs, SHADE, NEWPATH, reference-order box steps, and everything else
+// (votes, loop overhead) -- into the scheduling-statistics slots.
+template <bool LDS, bool COUNT, bool TIME = false>
 __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
     const DevScene& sc = a.sc;
     fillCounterLut();
@@ -739,7 +742,19 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
     int chunk = 0, chunkNext = 64;
     int chunkSample = 0, chunkX0 = 0, chunkY0 = 0;
     bool chunkInside = false;
+    unsigned int chunkAhead = 0;  // lane 0: the queue index fetched ahead of need
+    if (lane == 0) chunkAhead = atomicAdd(a.queue, 1u);
     unsigned long long schedExec[7] = {0, 0, 0, 0, 0, 0, 0}, schedLanes[7] = {0, 0, 0, 0, 0, 0, 0};
+    // TIME: ticks[0..4] per operation (OP_BOX .. OP_REFBOX), ticks[5] = the rest; tMark = last reading
+    unsigned long long ticks[6] = {0, 0, 0, 0, 0, 0}, tMark = 0;
+    auto lap = [&](int slot) {  // charges the time since the last reading to `slot`
+        if (TIME) {
+            const unsigned long long now = (unsigned long long)clock64();
+            ticks[slot] += now - tMark;
+            tMark = now;
+        }
+    };
+    if (TIME) tMark = (unsigned long long)clock64();
 
     auto startRay = [&]() {
         invx = 1.0f / r.d.x;
@@ -801,6 +816,7 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
             schedExec[slot] += 1;
             schedLanes[slot] += cnt[chosen];
         }
+        lap(5);
         if (chosen == OP_BOX || chosen == OP_PRIM) {
             // Traversal phase: box bursts and primitive tests alternate, with a two-ballot vote
             // between them, for as long as one of the two has more lanes waiting than all the
@@ -833,6 +849,7 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
                         boxStep();
                         boxStep();
                     } while (popc64(__ballot(op == OP_BOX)) >= keep && keep > 0);
+                    lap(OP_BOX);
                 } else {
                     auto primStep = [&]() {
                         if (op == OP_PRIM) {
@@ -875,6 +892,7 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
                     } else {
                         primStep();
                     }
+                    lap(OP_PRIM);
                 }
                 nBox = popc64(__ballot(op == OP_BOX));
                 const int nPrim = popc64(__ballot(op == OP_PRIM));
@@ -886,6 +904,7 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
                     schedExec[cur] += 1;
                     schedLanes[cur] += best;
                 }
+                lap(5);
             }
         } else if (chosen == OP_REFBOX) {
             // Reference-order array: the reference's own test; list entries have no box.
@@ -911,6 +930,7 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
                     }
                 }
             } while (popc64(__ballot(op == OP_REFBOX)) >= keep && keep > 0);
+            lap(OP_REFBOX);
         } else if (chosen == OP_SHADE) {
             if (op == OP_SHADE) {
                 if (mode == 0 && !guardsPass<COUNT>(sv, r, invx, invy, invz, h, &st)) {
@@ -935,6 +955,7 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
                     }
                 }
             }
+            lap(OP_SHADE);
         } else {  // OP_NEWPATH: the next unit for every waiting lane, in lane order, and its camera ray
             const bool want = op == OP_NEWPATH;
             if (want && depth > 0) {  // the path this lane holds ended on the background
@@ -942,13 +963,14 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
                 endPath(V3{sc.bg[0], sc.bg[1], sc.bg[2]});
             }
             const unsigned long long m = __ballot(want);
-            if (chunk >= 0 && chunkNext >= 64) {  // chunk used up: take the next one from the queue
-                unsigned int c = 0;
-                if (lane == 0) c = atomicAdd(a.queue, 1u);
-                c = __builtin_amdgcn_readfirstlane(c);
+            if (chunk >= 0 && chunkNext >= 64) {  // chunk used up: take the one fetched ahead
+                const unsigned int c = __builtin_amdgcn_readfirstlane(chunkAhead);
                 if (c >= nChunks) {
                     chunk = -1;  // the queue is dry
                 } else {
+                    // and fetch the one after it now: the atomic's round trip to L2 (thousands of
+                    // cycles) is over long before this wave needs the index
+                    if (lane == 0) chunkAhead = atomicAdd(a.queue, 1u);
                     chunk = (int)c;
                     chunkNext = 0;
                     // chunk -> (sample, tile) -> the tile's corner pixel, all wave-uniform
@@ -993,7 +1015,13 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
                 }      // else the chunk ran out before this lane's turn: it asks again
             }
             chunkNext += popc64(m);
+            lap(OP_NEWPATH);
         }
+    }
+    if (TIME && lane == 0) {
+        lap(5);
+        for (int i = 0; i < 6; i++) atomicAdd(&a.counters[13 + 2 * i], ticks[i]);
+        atomicAdd(&a.counters[14], 1ull);  // waves
     }
     if (COUNT && lane == 0) {
         for (int i = 0; i < 7; i++) {
@@ -1136,12 +1164,12 @@ __global__ void __launch_bounds__(256) resolveKernel(const float4* payloads, siz
 }
 
 // ------------------------------------------------------------------ launch wrappers
-template <bool LDS, bool COUNT>
+template <bool LDS, bool COUNT, bool TIME = false>
 static hipError_t launchWavefrontT(const RenderArgs& a, int blocks, int threads, size_t shmem, hipStream_t stream) {
     if (LDS)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(renderWavefront<LDS, COUNT>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(renderWavefront<LDS, COUNT, TIME>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    renderWavefront<LDS, COUNT><<<blocks, threads, shmem, stream>>>(a);
+    renderWavefront<LDS, COUNT, TIME><<<blocks, threads, shmem, stream>>>(a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const int nSlots = a.n_local_tiles * 64;
@@ -1151,6 +1179,9 @@ static hipError_t launchWavefrontT(const RenderArgs& a, int blocks, int threads,
 
 hipError_t launchWavefront(const RenderArgs& a, bool lds, bool count, int blocks, int threads, hipStream_t stream) {
     size_t shmem = lds ? (size_t)a.lds_bytes : 0;
+    if (count && a.timing)
+        return lds ? launchWavefrontT<true, false, true>(a, blocks, threads, shmem, stream)
+                   : launchWavefrontT<false, false, true>(a, blocks, threads, 0, stream);
     if (lds) return count ? launchWavefrontT<true, true>(a, blocks, threads, shmem, stream)
                           : launchWavefrontT<true, false>(a, blocks, threads, shmem, stream);
     return count ? launchWavefrontT<false, true>(a, blocks, threads, 0, stream)
