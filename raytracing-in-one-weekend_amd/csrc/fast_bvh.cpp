@@ -322,24 +322,6 @@ void Scene::buildFastStructure() {
         }
     }
 
-    // ---- the same guards as one record per primitive
-    f.guard_rec.assign((spheres.size() + triangles.size()) * 8, 0u);
-    auto record = [&](size_t slot, int32_t ord) {
-        uint32_t* w = &f.guard_rec[slot * 8];
-        w[3] = 0xFFFFFFFFu;
-        if (ord < 0) return;  // not in the world: never hit, never looked up
-        const int g = f.prim_guard[(size_t)ord];
-        if (g < 0) return;    // no box above it (a plain list): nothing to check
-        for (int k = 0; k < 3; k++) {
-            w[k] = f.nodes[(size_t)g * 8 + k];
-            w[4 + k] = f.nodes[(size_t)g * 8 + 4 + k];
-        }
-        w[3] = (uint32_t)f.node_outer[(size_t)g];
-        w[7] = 1u;
-    };
-    for (size_t i = 0; i < spheres.size(); i++) record(i, f.sphere_ord[i]);
-    for (size_t i = 0; i < triangles.size(); i++) record(spheres.size() + i, f.tri_ord[i]);
-
     // ---- padded primitive boxes.  The padding is orders of magnitude above the rounding error of
     // the hit-distance arithmetic (which is worst for the radius-1000 ground sphere), so a
     // primitive whose computed hit distance is accepted always lies inside its padded box.

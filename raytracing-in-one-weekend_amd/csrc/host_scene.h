@@ -70,10 +70,6 @@ struct FlatScene {
     std::vector<int32_t> tri_ord;       // triangle id -> position in prim_refs
     std::vector<int32_t> prim_guard;    // position in prim_refs -> innermost box-tested entry of `nodes` above it, or -1
     std::vector<int32_t> node_outer;    // entry of `nodes` -> nearest enclosing box-tested entry whose box does not contain it, or -1
-    // Per primitive (spheres, then triangles, by id) the guard box itself, so that the check needs one
-    // fetch instead of a chain of three: 8 words {min.xyz, node_outer of the guard entry | -1},
-    // {max.xyz, 1 if there is a guard box else 0}
-    std::vector<uint32_t> guard_rec;
 };
 
 constexpr uint32_t kNodeNoBox = 1u << 30;     // entry without a box test

@@ -506,9 +506,6 @@ int rt_upload_scene(rt_context* ctx, rt_scene* s) {
     if ((rc = devUpload(ctx, sc.flat.tri_ord, &d.tri_ord))) return rc;
     if ((rc = devUpload(ctx, sc.flat.prim_guard, &d.prim_guard))) return rc;
     if ((rc = devUpload(ctx, sc.flat.node_outer, &d.node_outer))) return rc;
-    std::vector<float4> guardRec(sc.flat.guard_rec.size() / 4);
-    std::memcpy(guardRec.data(), sc.flat.guard_rec.data(), sc.flat.guard_rec.size() * 4);
-    if ((rc = devUpload(ctx, guardRec, &d.guard_rec))) return rc;
     if ((rc = devUpload(ctx, spheres, &d.spheres))) return rc;
     if ((rc = devUpload(ctx, sphereMat, &d.sphere_mat))) return rc;
     if ((rc = devUpload(ctx, triI, &d.tri_isect))) return rc;

@@ -18,7 +18,6 @@ struct DevScene {
     const int* tri_ord;       // triangle id -> position in prim_refs
     const int* prim_guard;    // position in prim_refs -> innermost box-tested entry of `nodes` above it, or -1
     const int* node_outer;    // entry of `nodes` -> next enclosing entry that must be checked too, or -1
-    const float4* guard_rec;  // per primitive (spheres, then triangles): {min.xyz, node_outer | -1}, {max.xyz, has box}
     // primitives and materials
     const float4* spheres;    // {c.xyz, r}
     const int* sphere_mat;

@@ -105,13 +105,11 @@ struct SceneView {
     const int* tri_ord;
     const int* prim_guard;
     const int* node_outer;
-    const float4* guard_rec;  // always in global memory
-    int n_spheres;
 };
 
 __device__ __forceinline__ SceneView globalView(const DevScene& sc) {
     return SceneView{sc.nodes,      sc.prim_refs, sc.fast_nodes, sc.fast_refs,  sc.spheres,    sc.tri_isect, sc.sphere_mat,
-                     sc.tri_mat,    sc.materials, sc.sphere_ord, sc.tri_ord,    sc.prim_guard, sc.node_outer, sc.guard_rec, sc.n_spheres};
+                     sc.tri_mat,    sc.materials, sc.sphere_ord, sc.tri_ord,    sc.prim_guard, sc.node_outer};
 }
 
 constexpr int kNumStats = 14;
@@ -322,14 +320,7 @@ __device__ __forceinline__ Hit traverseFast(const SceneView& sv, int n_nodes, co
 template <bool COUNT>
 __device__ __forceinline__ bool guardsPass(const SceneView& sv, const Ray& r, float invx, float invy, float invz, const Hit& h,
                                            Stats* st) {
-    // the innermost box comes with the primitive's own record (one fetch instead of the chain
-    // visit order -> guard entry -> its box); further boxes, if any, from the reference entries
-    const int slot = (int)(h.ref & kRefId) + ((h.ref & kRefTri) ? sv.n_spheres : 0);
-    const float4 g0 = sv.guard_rec[2 * slot], g1 = sv.guard_rec[2 * slot + 1];
-    if (fbits(g1.w) == 0u) return true;  // no box above this primitive
-    if (COUNT) st->v[C_NODE]++;
-    if (!slabPass(g0, g1, r, invx, invy, invz, h.t)) return false;
-    int g = (int)fbits(g0.w);
+    int g = sv.prim_guard[refOrder(sv, h.ref)];
     while (g >= 0) {
         if (COUNT) st->v[C_NODE]++;
         if (!slabPass(sv.nodes[2 * g], sv.nodes[2 * g + 1], r, invx, invy, invz, h.t)) return false;
@@ -604,8 +595,6 @@ __device__ __forceinline__ SceneView stageScene(const DevScene& sc, bool withRef
         v.prim_guard = sc.prim_guard;
         v.node_outer = sc.node_outer;
     }
-    v.guard_rec = sc.guard_rec;
-    v.n_spheres = sc.n_spheres;
     __syncthreads();
     return v;
 }
@@ -756,9 +745,8 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
     unsigned int chunkAhead = 0;  // lane 0: the queue index fetched ahead of need
     if (lane == 0) chunkAhead = atomicAdd(a.queue, 1u);
     unsigned long long schedExec[7] = {0, 0, 0, 0, 0, 0, 0}, schedLanes[7] = {0, 0, 0, 0, 0, 0, 0};
-    // TIME: ticks per stretch of the loop (T_* below); tMark = last reading
-    enum { T_BOX, T_PRIM, T_GUARD, T_SURFACE, T_SCATTER, T_SHADE_TAIL, T_FINISH, T_REFILL, T_CAMERA, T_REFBOX, T_REST, T_N };
-    unsigned long long ticks[T_N] = {0}, tMark = 0;
+    // TIME: ticks[0..4] per operation (OP_BOX .. OP_REFBOX), ticks[5] = the rest; tMark = last reading
+    unsigned long long ticks[6] = {0, 0, 0, 0, 0, 0}, tMark = 0;
     auto lap = [&](int slot) {  // charges the time since the last reading to `slot`
         if (TIME) {
             const unsigned long long now = (unsigned long long)clock64();
@@ -828,7 +816,7 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
             schedExec[slot] += 1;
             schedLanes[slot] += cnt[chosen];
         }
-        lap(T_REST);
+        lap(5);
         if (chosen == OP_BOX || chosen == OP_PRIM) {
             // Traversal phase: box bursts and primitive tests alternate, with a two-ballot vote
             // between them, for as long as one of the two has more lanes waiting than all the
@@ -861,7 +849,7 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
                         boxStep();
                         boxStep();
                     } while (popc64(__ballot(op == OP_BOX)) >= keep && keep > 0);
-                    lap(T_BOX);
+                    lap(OP_BOX);
                 } else {
                     auto primStep = [&]() {
                         if (op == OP_PRIM) {
@@ -904,7 +892,7 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
                     } else {
                         primStep();
                     }
-                    lap(T_PRIM);
+                    lap(OP_PRIM);
                 }
                 nBox = popc64(__ballot(op == OP_BOX));
                 const int nPrim = popc64(__ballot(op == OP_PRIM));
@@ -916,7 +904,7 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
                     schedExec[cur] += 1;
                     schedLanes[cur] += best;
                 }
-                lap(T_REST);
+                lap(5);
             }
         } else if (chosen == OP_REFBOX) {
             // Reference-order array: the reference's own test; list entries have no box.
@@ -942,22 +930,17 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
                     }
                 }
             } while (popc64(__ballot(op == OP_REFBOX)) >= keep && keep > 0);
-            lap(T_REFBOX);
+            lap(OP_REFBOX);
         } else if (chosen == OP_SHADE) {
             if (op == OP_SHADE) {
-                const bool vouched = mode != 0 || guardsPass<COUNT>(sv, r, invx, invy, invz, h, &st);
-                lap(T_GUARD);
-                if (!vouched) {
+                if (mode == 0 && !guardsPass<COUNT>(sv, r, invx, invy, invz, h, &st)) {
                     retraceInReferenceOrder();
                 } else {
                     if (COUNT) st.v[C_HITS]++;
                     Surface sf = surfaceAt(sc, sv, r, h);
-                    lap(T_SURFACE);
                     Ray out;
                     V3 atten, emit;
-                    const bool alive = scatter<COUNT>(sc, sv, r, sf, rng, out, atten, emit, &st);
-                    lap(T_SCATTER);
-                    if (!alive) {
+                    if (!scatter<COUNT>(sc, sv, r, sf, rng, out, atten, emit, &st)) {
                         endPath(emit);
                     } else {
                         thr = thr * atten;
@@ -972,14 +955,13 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
                     }
                 }
             }
-            lap(T_SHADE_TAIL);
+            lap(OP_SHADE);
         } else {  // OP_NEWPATH: the next unit for every waiting lane, in lane order, and its camera ray
             const bool want = op == OP_NEWPATH;
             if (want && depth > 0) {  // the path this lane holds ended on the background
                 if (COUNT) st.v[C_MISS]++;
                 endPath(V3{sc.bg[0], sc.bg[1], sc.bg[2]});
             }
-            lap(T_FINISH);
             const unsigned long long m = __ballot(want);
             if (chunk >= 0 && chunkNext >= 64) {  // chunk used up: take the one fetched ahead
                 const unsigned int c = __builtin_amdgcn_readfirstlane(chunkAhead);
@@ -1005,7 +987,6 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
                     chunkInside = tx < a.tiles_x;
                 }
             }
-            lap(T_REFILL);
             if (want) {
                 const int rankInMask =
                     __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
@@ -1034,13 +1015,13 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
                 }      // else the chunk ran out before this lane's turn: it asks again
             }
             chunkNext += popc64(m);
-            lap(T_CAMERA);
+            lap(OP_NEWPATH);
         }
     }
     if (TIME && lane == 0) {
-        lap(T_REST);
-        for (int i = 0; i < T_N; i++) atomicAdd(&a.counters[13 + i], ticks[i]);
-        atomicAdd(&a.counters[26], 1ull);  // waves
+        lap(5);
+        for (int i = 0; i < 6; i++) atomicAdd(&a.counters[13 + 2 * i], ticks[i]);
+        atomicAdd(&a.counters[14], 1ull);  // waves
     }
     if (COUNT && lane == 0) {
         for (int i = 0; i < 7; i++) {
