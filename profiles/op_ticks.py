@@ -28,11 +28,13 @@ ctx.upload_scene(s)
 ctx.set_target(W, H)
 ctx.count(0, spp, 50)
 st = ctx.sched_stats()
-vals = list(st.values())
-names = ["box bursts", "primitive runs", "shade", "newpath", "reference-order box steps", "votes and the rest"]
-ticks = [vals[i][0] for i in range(6)]
-waves = vals[0][1]
+vals = [x for pair in st.values() for x in pair]   # the 14 raw slots
+names = ["box bursts", "primitive runs", "shade: guard test", "shade: surface", "shade: scatter",
+         "shade: next ray / end of path", "newpath: finish missed path", "newpath: queue refill",
+         "newpath: camera ray", "reference-order box steps", "votes and the rest"]
+ticks = vals[:len(names)]
+waves = vals[13]
 total = sum(ticks)
 print(f"{which}: {waves} waves, {total / max(waves, 1):.0f} ticks per wave")
 for n, t in zip(names, ticks):
-    print(f"  {n:28s} {100.0 * t / max(total, 1):5.1f} %")
+    print(f"  {n:32s} {100.0 * t / max(total, 1):5.1f} %")

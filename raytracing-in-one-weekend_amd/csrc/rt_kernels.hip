@@ -745,8 +745,9 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
     unsigned int chunkAhead = 0;  // lane 0: the queue index fetched ahead of need
     if (lane == 0) chunkAhead = atomicAdd(a.queue, 1u);
     unsigned long long schedExec[7] = {0, 0, 0, 0, 0, 0, 0}, schedLanes[7] = {0, 0, 0, 0, 0, 0, 0};
-    // TIME: ticks[0..4] per operation (OP_BOX .. OP_REFBOX), ticks[5] = the rest; tMark = last reading
-    unsigned long long ticks[6] = {0, 0, 0, 0, 0, 0}, tMark = 0;
+    // TIME: ticks per stretch of the loop (T_* below); tMark = last reading
+    enum { T_BOX, T_PRIM, T_GUARD, T_SURFACE, T_SCATTER, T_SHADE_TAIL, T_FINISH, T_REFILL, T_CAMERA, T_REFBOX, T_REST, T_N };
+    unsigned long long ticks[T_N] = {0}, tMark = 0;
     auto lap = [&](int slot) {  // charges the time since the last reading to `slot`
         if (TIME) {
             const unsigned long long now = (unsigned long long)clock64();
@@ -816,7 +817,7 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
             schedExec[slot] += 1;
             schedLanes[slot] += cnt[chosen];
         }
-        lap(5);
+        lap(T_REST);
         if (chosen == OP_BOX || chosen == OP_PRIM) {
             // Traversal phase: box bursts and primitive tests alternate, with a two-ballot vote
             // between them, for as long as one of the two has more lanes waiting than all the
@@ -849,7 +850,7 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
                         boxStep();
                         boxStep();
                     } while (popc64(__ballot(op == OP_BOX)) >= keep && keep > 0);
-                    lap(OP_BOX);
+                    lap(T_BOX);
                 } else {
                     auto primStep = [&]() {
                         if (op == OP_PRIM) {
@@ -892,7 +893,7 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
                     } else {
                         primStep();
                     }
-                    lap(OP_PRIM);
+                    lap(T_PRIM);
                 }
                 nBox = popc64(__ballot(op == OP_BOX));
                 const int nPrim = popc64(__ballot(op == OP_PRIM));
@@ -904,7 +905,7 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
                     schedExec[cur] += 1;
                     schedLanes[cur] += best;
                 }
-                lap(5);
+                lap(T_REST);
             }
         } else if (chosen == OP_REFBOX) {
             // Reference-order array: the reference's own test; list entries have no box.
@@ -930,17 +931,22 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
                     }
                 }
             } while (popc64(__ballot(op == OP_REFBOX)) >= keep && keep > 0);
-            lap(OP_REFBOX);
+            lap(T_REFBOX);
         } else if (chosen == OP_SHADE) {
             if (op == OP_SHADE) {
-                if (mode == 0 && !guardsPass<COUNT>(sv, r, invx, invy, invz, h, &st)) {
+                const bool vouched = mode != 0 || guardsPass<COUNT>(sv, r, invx, invy, invz, h, &st);
+                lap(T_GUARD);
+                if (!vouched) {
                     retraceInReferenceOrder();
                 } else {
                     if (COUNT) st.v[C_HITS]++;
                     Surface sf = surfaceAt(sc, sv, r, h);
+                    lap(T_SURFACE);
                     Ray out;
                     V3 atten, emit;
-                    if (!scatter<COUNT>(sc, sv, r, sf, rng, out, atten, emit, &st)) {
+                    const bool alive = scatter<COUNT>(sc, sv, r, sf, rng, out, atten, emit, &st);
+                    lap(T_SCATTER);
+                    if (!alive) {
                         endPath(emit);
                     } else {
                         thr = thr * atten;
@@ -955,13 +961,14 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
                     }
                 }
             }
-            lap(OP_SHADE);
+            lap(T_SHADE_TAIL);
         } else {  // OP_NEWPATH: the next unit for every waiting lane, in lane order, and its camera ray
             const bool want = op == OP_NEWPATH;
             if (want && depth > 0) {  // the path this lane holds ended on the background
                 if (COUNT) st.v[C_MISS]++;
                 endPath(V3{sc.bg[0], sc.bg[1], sc.bg[2]});
             }
+            lap(T_FINISH);
             const unsigned long long m = __ballot(want);
             if (chunk >= 0 && chunkNext >= 64) {  // chunk used up: take the one fetched ahead
                 const unsigned int c = __builtin_amdgcn_readfirstlane(chunkAhead);
@@ -987,6 +994,7 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
                     chunkInside = tx < a.tiles_x;
                 }
             }
+            lap(T_REFILL);
             if (want) {
                 const int rankInMask =
                     __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
@@ -1015,13 +1023,13 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
                 }      // else the chunk ran out before this lane's turn: it asks again
             }
             chunkNext += popc64(m);
-            lap(OP_NEWPATH);
+            lap(T_CAMERA);
         }
     }
     if (TIME && lane == 0) {
-        lap(5);
-        for (int i = 0; i < 6; i++) atomicAdd(&a.counters[13 + 2 * i], ticks[i]);
-        atomicAdd(&a.counters[14], 1ull);  // waves
+        lap(T_REST);
+        for (int i = 0; i < T_N; i++) atomicAdd(&a.counters[13 + i], ticks[i]);
+        atomicAdd(&a.counters[26], 1ull);  // waves
     }
     if (COUNT && lane == 0) {
         for (int i = 0; i < 7; i++) {
