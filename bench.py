@@ -205,7 +205,7 @@ def main():
             "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_FP32_TFLOPS, 4),
             "traffic": hbm_traffic_bytes(world, args.spp),
-            "kernel": "rt::renderWavefront<true, false>",
+            "kernel": "rt::renderWavefront<true, false, false>",
             "kernel_ms": round(avg_kernel_ms, 4),
             "flops_per_sample": round(flops_per_sample, 1),
             "rays_per_sample": round(counters["rays"] / counters["samples"], 3),

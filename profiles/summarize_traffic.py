@@ -18,7 +18,7 @@ def per_dispatch(root, counter):
     for db_path in sorted(glob.glob(os.path.join(root, "*", "*_results.db"))):
         cur = sqlite3.connect(db_path).cursor()
         total, found = 0.0, False
-        for pattern in ("%renderWavefront<true, false>%", "%accumulateColors%"):
+        for pattern in ("%renderWavefront<true, false, false>%", "%accumulateColors%"):
             try:
                 rows = list(cur.execute(
                     "select sum(value) / count(distinct dispatch_id) from counters_collection "
