@@ -26,7 +26,9 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <limits>
+#include <thread>
 
 #include "host_scene.h"
 
@@ -82,7 +84,12 @@ struct Builder {
         int left, right;  // -1: leaf over prims[start, end)
         size_t start, end;
     };
+    // the tree is sized up front and its slots are handed out by an atomic counter, so that subtrees
+    // (disjoint ranges of `prims`) can be built by different threads; the emission below depends on
+    // the tree's shape only, never on which slot a node got
     std::vector<TNode> tree;
+    std::atomic<int> nextSlot{0};
+    std::atomic<int> spareThreads{0};
 
     int newEntry(const float* mn, const float* mx) {
         int idx = (int)(nodes.size() / 8);
@@ -105,8 +112,8 @@ struct Builder {
                 cmx[k] = std::max(cmx[k], c);
             }
         }
-        const int t = (int)tree.size();
-        tree.push_back(TNode{{mn[0], mn[1], mn[2]}, {mx[0], mx[1], mx[2]}, area(mn, mx), -1, -1, start, end});
+        const int t = nextSlot.fetch_add(1);
+        tree[t] = TNode{{mn[0], mn[1], mn[2]}, {mx[0], mx[1], mx[2]}, area(mn, mx), -1, -1, start, end};
         const size_t n = end - start;
         if (n <= (size_t)kMaxLeaf) return t;
         size_t mid = 0;
@@ -180,8 +187,17 @@ struct Builder {
             mid = (size_t)(it - prims.begin());
             if (mid == start || mid == end) mid = start + n / 2;
         }
-        const int l = build(start, mid);
-        const int r = build(mid, end);
+        int l, r;
+        if (n >= 32768 && spareThreads.fetch_sub(1) > 0) {
+            std::thread other([&] { l = build(start, mid); });
+            r = build(mid, end);
+            other.join();
+            spareThreads.fetch_add(1);
+        } else {
+            if (n >= 32768) spareThreads.fetch_add(1);  // nothing was taken
+            l = build(start, mid);
+            r = build(mid, end);
+        }
         tree[t].left = l;
         tree[t].right = r;
         return t;
@@ -252,6 +268,8 @@ struct Builder {
     }
 
     void run() {
+        tree.resize(2 * prims.size());
+        spareThreads = (int)buildThreads() - 1;
         const int root = build(0, prims.size());
         std::vector<int> top;
         gather(root, tree[root].area, top);  // the root itself goes when it is an inner entry

@@ -4,6 +4,11 @@
 // the operation orders used for dot / cross / normalize / mat4*vec4 / inverse are glm
 // 0.9.9's scalar code paths as commonly documented.
 // R/ = /root/reference/Raytracing-In-A-Weekend/.
+#include <chrono>
+#include <cstdio>
+#include <atomic>
+#include <map>
+#include <thread>
 #include "host_scene.h"
 
 #include <algorithm>
@@ -380,11 +385,32 @@ Box3 Scene::objectBox(const Obj& o) const {
 // The objects travel with their bounding boxes, computed once: boxCompare (Bvh.cpp:3-12) calls
 // BoundingBox() on both operands of every comparison, and std::sort's permutation depends only
 // on the outcomes of the comparisons, which are the same on the stored boxes.
-int Scene::buildBvh(Composite& c, std::vector<BoxedObj>& objs, size_t start, size_t end, int max_depth) {
-    int axis = randomInt(0, 2);
+// Number of BVHNode objects the constructor creates for `span` objects with `max_depth` levels left
+// (Bvh.h:17-67): one for the node itself, and two subtrees unless the span is at most 2 or the
+// depth limit makes the halves plain lists.  Spans on one level differ by at most one, so the
+// recursion with a memo visits O(levels) distinct arguments.
+static size_t bvhNodeCount(size_t span, int max_depth) {
+    thread_local std::map<std::pair<size_t, int>, size_t> memo;
+    if (span <= 2 || max_depth == 0) return 1;
+    const int d = max_depth < 0 ? -1 : max_depth;
+    auto key = std::make_pair(span, d);
+    auto it = memo.find(key);
+    if (it != memo.end()) return it->second;
+    const size_t n = 1 + bvhNodeCount(span / 2, max_depth - 1) + bvhNodeCount(span - span / 2, max_depth - 1);
+    memo[key] = n;
+    return n;
+}
+
+// BVHNode::BVHNode (Bvh.h:17-67) over objs[start, end).  The constructor draws its axis before it
+// recurses (left subtree first), so node k in pre-order uses the k-th draw: the draws are made up
+// front, in order, from the scene's generator (which ends in the same state), and the node with
+// pre-order index `me` reads axes[me].  Everything else a node does touches only its own range of
+// `objs` and its own slots of c.nodes, so the two halves can be built by different threads; the
+// result does not depend on how the work is spread.
+void Scene::buildBvhAt(Composite& c, std::vector<BoxedObj>& objs, size_t start, size_t end, int max_depth, size_t me,
+                       const std::vector<uint8_t>& axes, std::atomic<int>& spare_threads) {
+    const int axis = axes[me];
     auto less = [axis](const BoxedObj& a, const BoxedObj& b) { return a.box.mn[axis] < b.box.mn[axis]; };
-    int me = (int)c.nodes.size();
-    c.nodes.emplace_back();
     size_t span = end - start;
     Box3 bl, br;
     if (span == 1) {
@@ -411,16 +437,43 @@ int Scene::buildBvh(Composite& c, std::vector<BoxedObj>& objs, size_t start, siz
             for (size_t i = mid + 1; i < end; i++) br = unionBox(br, objs[i].box);
             c.nodes[me].leaf = std::move(leaf);
         } else {
-            int l = buildBvh(c, objs, start, mid, max_depth - 1);
-            int r = buildBvh(c, objs, mid, end, max_depth - 1);
-            c.nodes[me].left = l;
-            c.nodes[me].right = r;
+            const size_t l = me + 1;
+            const size_t r = l + bvhNodeCount(mid - start, max_depth - 1);
+            if (span >= 32768 && spare_threads.fetch_sub(1) > 0) {
+                std::thread other([&] { buildBvhAt(c, objs, start, mid, max_depth - 1, l, axes, spare_threads); });
+                buildBvhAt(c, objs, mid, end, max_depth - 1, r, axes, spare_threads);
+                other.join();
+                spare_threads.fetch_add(1);
+            } else {
+                if (span >= 32768) spare_threads.fetch_add(1);  // nothing was taken
+                buildBvhAt(c, objs, start, mid, max_depth - 1, l, axes, spare_threads);
+                buildBvhAt(c, objs, mid, end, max_depth - 1, r, axes, spare_threads);
+            }
+            c.nodes[me].left = (int)l;
+            c.nodes[me].right = (int)r;
             bl = c.nodes[l].box;
             br = c.nodes[r].box;
         }
     }
     c.nodes[me].box = unionBox(bl, br);
-    return me;
+}
+
+int Scene::buildBvh(Composite& c, std::vector<BoxedObj>& objs, size_t start, size_t end, int max_depth) {
+    const size_t total = bvhNodeCount(end - start, max_depth);
+    std::vector<uint8_t> axes(total);
+    for (size_t i = 0; i < total; i++) axes[i] = (uint8_t)randomInt(0, 2);
+    const size_t base = c.nodes.size();
+    c.nodes.resize(base + total);
+    std::atomic<int> spare((int)buildThreads() - 1);
+    buildBvhAt(c, objs, start, end, max_depth, base, axes, spare);
+    return (int)base;
+}
+
+// Threads the host-side builders may use: the machine's, at most 16 (RT_BUILD_THREADS overrides).
+unsigned buildThreads() {
+    if (const char* e = std::getenv("RT_BUILD_THREADS")) return (unsigned)std::max(1, std::atoi(e));
+    if (const char* e = std::getenv("OMP_NUM_THREADS")) return (unsigned)std::min(16, std::max(1, std::atoi(e)));
+    return std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
 }
 
 std::vector<Scene::BoxedObj> Scene::withBoxes(const std::vector<Obj>& objs) const {

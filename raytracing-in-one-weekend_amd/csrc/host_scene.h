@@ -1,6 +1,7 @@
 // Host-side scene construction and the BVH flatten step (no device code here).
 // R/ = /root/reference/Raytracing-In-A-Weekend/ in the citations below.
 #pragma once
+#include <atomic>
 #include <cstdint>
 #include <random>
 #include <string>
@@ -82,6 +83,8 @@ struct Camera22 {
     float origin[3], llc[3], horizontal[3], vertical[3], u[3], v[3], w[3], lens_radius;
 };
 
+unsigned buildThreads();  // threads the host-side builders may use
+
 class Scene {
 public:
     Scene();
@@ -129,6 +132,8 @@ private:
     };
     std::vector<BoxedObj> withBoxes(const std::vector<Obj>& objs) const;
     int buildBvh(Composite& c, std::vector<BoxedObj>& objs, size_t start, size_t end, int max_depth);
+    void buildBvhAt(Composite& c, std::vector<BoxedObj>& objs, size_t start, size_t end, int max_depth, size_t me,
+                    const std::vector<uint8_t>& axes, std::atomic<int>& spare_threads);
     void emitObjects(const std::vector<Obj>& objs, int parent_entry);
     void emitComposite(const Composite& c);
     void emitBvhNode(const Composite& c, int node);

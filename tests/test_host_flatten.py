@@ -207,3 +207,33 @@ def test_empty_world_flattens_to_one_boxless_entry(rt):
     d = s.get_flat()
     assert d["info"].n_nodes == 1 and d["info"].n_prim_refs == 0
     assert d["nodes"][0, 3] == ((1 << 30) | 1) and d["nodes"][0, 7] == 0xFFFFFFFF
+
+
+def test_threaded_build_equals_the_serial_one_and_the_oracle(rt, orc, monkeypatch):
+    """Ranges of 32,768 objects and more are built by several threads (both the reference-order BVH,
+    whose axis draws are made up front in pre-order, and the search structure).  The result must not
+    depend on the number of threads, and the reference-order arrays must still be the oracle's."""
+    def build(s):
+        m = s.add_material(0, (0.5, 0.5, 0.5))
+        rr = np.random.RandomState(17)
+        c = (rr.rand(70000, 3) * 1000).astype(np.float32)
+        rad = (0.5 + 3 * rr.rand(70000)).astype(np.float32)
+        for i in range(70000):
+            s.add_sphere(c[i], float(rad[i]), m)
+        s.wrap_bvh()
+
+    monkeypatch.setenv("RT_BUILD_THREADS", "8")
+    a, b = build_both(rt, orc, build)
+    flat = a.get_flat()
+    ea, ra = a.search_structure()
+    after_a = a.rng_floats(4)
+    monkeypatch.setenv("RT_BUILD_THREADS", "1")
+    c = rt.Scene()
+    build(c)
+    flat_c = c.get_flat()
+    ec, rc = c.search_structure()
+    assert np.array_equal(flat["nodes"], flat_c["nodes"]) and np.array_equal(flat["prim_refs"], flat_c["prim_refs"])
+    assert np.array_equal(ea, ec) and np.array_equal(ra, rc)
+    assert np.array_equal(after_a.view(np.uint32), c.rng_floats(4).view(np.uint32))   # same generator state
+    check_structure(flat, *b.dump_tree())
+    assert np.array_equal(after_a.view(np.uint32), b.rng_floats(4).view(np.uint32))
