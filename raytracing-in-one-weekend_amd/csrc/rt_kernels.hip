@@ -161,10 +161,8 @@ __device__ __forceinline__ bool slabPassFast(const float4& a, const float4& b, f
     const f32x2 ty = __builtin_elementwise_fma(f32x2{a.z, a.w}, f32x2{invy, invy}, f32x2{noy, noy});
     const f32x2 tz = __builtin_elementwise_fma(f32x2{b.x, b.y}, f32x2{invz, invz}, f32x2{noz, noz});
     const float tn = fmaxf(fmaxf(fminf(tx.x, tx.y), fminf(ty.x, ty.y)), fmaxf(fminf(tz.x, tz.y), kTMin));
-    // `closest` is compared on its own: folded into the min chain it would be quieted (an extra
-    // instruction) at every step, as the compiler cannot see that it never holds a signalling NaN
-    const float tf = fminf(fminf(fmaxf(tx.x, tx.y), fmaxf(ty.x, ty.y)), fmaxf(tz.x, tz.y));
-    return (tn <= tf) & (tn <= closest);
+    const float tf = fminf(fminf(fmaxf(tx.x, tx.y), fmaxf(ty.x, ty.y)), fminf(fmaxf(tz.x, tz.y), closest));
+    return tn <= tf;
 }
 
 // Sphere::Hit / Triangle::Hit (R/src/Core/Hittable.h:228-255, 58-141) for one leaf reference:
