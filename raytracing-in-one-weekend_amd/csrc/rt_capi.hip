@@ -498,9 +498,7 @@ int rt_upload_scene(rt_context* ctx, rt_scene* s) {
     std::memcpy(nodes.data(), sc.flat.nodes.data(), sc.flat.nodes.size() * 4);
     if ((rc = devUpload(ctx, nodes, &d.nodes))) return rc;
     if ((rc = devUpload(ctx, sc.flat.prim_refs, &d.prim_refs))) return rc;
-    // two float4 more than the entries: the wavefront loop fetches the entry after the one it has
-    // just left, also when that was the last
-    std::vector<float4> fastNodes(sc.flat.fast_nodes.size() / 4 + 2, make_float4(0.f, 0.f, 0.f, 0.f));
+    std::vector<float4> fastNodes(sc.flat.fast_nodes.size() / 4);
     std::memcpy(fastNodes.data(), sc.flat.fast_nodes.data(), sc.flat.fast_nodes.size() * 4);
     if ((rc = devUpload(ctx, fastNodes, &d.fast_nodes))) return rc;
     if ((rc = devUpload(ctx, sc.flat.fast_refs, &d.fast_refs))) return rc;

@@ -698,9 +698,6 @@ __device__ __forceinline__ int popc64(unsigned long long m) {
 // 512-thread workgroups, three per CU = 6 waves per SIMD (80 registers per lane, a few cold values
 // spilled).  Measured on the cover scene: 4 waves per SIMD 37.6 ms, 6 waves 33.1 ms, 8 waves
 // (64 registers, heavy spilling) 60 ms.
-#ifndef BOX_STEPS_PER_LOOK
-#define BOX_STEPS_PER_LOOK 4
-#endif
 #ifndef WF_BOUNDS
 #define WF_BOUNDS 512, 6
 #endif
@@ -832,42 +829,26 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
                     // Search structure: conservative fused box test.  An entry that passes and carries
                     // a leaf run sends the lane to PRIM; `idx` already names the entry to go on with.
                     const int keep = boxKeep < nBox ? boxKeep : nBox;  // never spin below what is available
-                    // The step is one dependent chain (fetch, test, next index), and a wave issues in
-                    // order: the fetch for the NEXT step goes out as soon as the index is known, before
-                    // the bookkeeping of this step, so that its latency runs under the bookkeeping and the
-                    // loop overhead.  (The array has one spare entry at the end for the fetch of a lane
-                    // whose walk has just ended.)
-                    // Two register sets take turns (one holds the entry under test, the other receives
-                    // the next one), so nothing has to be copied out of the way of the incoming data.
-                    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, b0 = a0, b1 = a0;
-                    if (op == OP_BOX) {
-                        a0 = sv.fnodes[2 * idx];
-                        a1 = sv.fnodes[2 * idx + 1];
-                    }
-                    auto boxStep = [&](const float4& n0, const float4& n1, float4& m0, float4& m1) {
+                    auto boxStep = [&]() {
                         if (COUNT) {
                             schedExec[5] += 1;
                             schedLanes[5] += popc64(__ballot(op == OP_BOX));
                         }
                         if (op == OP_BOX) {
+                            const float4 n0 = sv.fnodes[2 * idx], n1 = sv.fnodes[2 * idx + 1];
                             const int first = (int)fbits(n1.w);
                             if (COUNT) st.v[C_NODE]++;
                             const bool pass = slabPassFast(n0, n1, invx, invy, invz, nox, noy, noz, h.t);
                             idx = pass ? idx + 1 : (int)fbits(n1.z);
-                            m0 = sv.fnodes[2 * idx];
-                            m1 = sv.fnodes[2 * idx + 1];
                             p = first;  // read by PRIM only, which a lane enters with its leaf run's start
                             const int onward = idx >= nNodesFast ? afterWalk() : OP_BOX;
                             op = (pass & (first >= 0)) ? OP_PRIM : onward;
                         }
                     };
-                    do {  // an even number of steps per look at the lane count
-                        boxStep(a0, a1, b0, b1);
-                        boxStep(b0, b1, a0, a1);
-#if BOX_STEPS_PER_LOOK == 4
-                        boxStep(a0, a1, b0, b1);
-                        boxStep(b0, b1, a0, a1);
-#endif
+                    do {  // three steps per look at the lane count (1: 32.35 ms, 2: 31.75, 3: 31.6, 4: 31.7)
+                        boxStep();
+                        boxStep();
+                        boxStep();
                     } while (popc64(__ballot(op == OP_BOX)) >= keep && keep > 0);
                     lap(T_BOX);
                 } else {
