@@ -91,7 +91,7 @@ def c4():
     run("C4 cover 3840x2160x1024", lambda s: scenes.cover_scene(s, 3840, 2160), 3840, 2160, 1024, [1080], oracle_spp=2)
 
 
-def c5s(n_tris, w=1920, h=1080, spp=16):
+def c5s(n_tris, w=1920, h=1080, spp=16, check=True):
     mesh = scenes.load_gltf_mesh(G)
     per = mesh["indices"].shape[0]
     copies = max(1, n_tris // per)
@@ -119,7 +119,7 @@ def c5s(n_tris, w=1920, h=1080, spp=16):
         s.set_camera((278.0, 400.0, -800.0), (278.0, 150.0, 300.0), (0.0, 1.0, 0.0), 40.0, 1.0, 0.0, 10.0)
         s.set_background((0.6, 0.7, 0.9))
 
-    run(f"C5 {copies} vases = {copies * per} triangles, {w}x{h}x{spp}", build, w, h, spp, [h // 2], oracle_spp=1)
+    run(f"C5 {copies} vases = {copies * per} triangles, {w}x{h}x{spp}", build, w, h, spp, [h // 2] if check else [], oracle_spp=1)
 
 
 def heartbeat():
@@ -144,6 +144,7 @@ if __name__ == "__main__":
         elif a == "c4":
             c4()
         elif a.startswith("c5s"):
-            c5s(int(float(a.split(":")[1])) if ":" in a else 1_000_000)
+            parts = a.split(":")   # c5s[:triangles[:nocheck]] -- nocheck skips the oracle rows (profiling runs)
+            c5s(int(float(parts[1])) if len(parts) > 1 else 1_000_000, check=not (len(parts) > 2 and parts[2] == "nocheck"))
         elif a.startswith("c5"):
             c5s(int(float(a.split(":")[1])) if ":" in a else 10_000_000, 3840, 2160, 256)
