@@ -42,6 +42,18 @@ def flops_from_counters(c):
     return float(sum(c[k] * v for k, v in COST.items()))
 
 
+SHADER_CLOCK_HZ = 2.4e9  # MI355X peak engine clock, the one the 157.3 TFLOP/s figure is quoted at
+
+
+def profiled(world, spp, key):
+    """A figure of the committed PMC passes (profiles/hbm_traffic.json) for the profiled configuration."""
+    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if world != 1 or spp != SPP or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f).get(key)
+
+
 def hbm_traffic_bytes(world, spp):
     """HBM bytes per render launch from the committed rocprofv3 PMC passes (profiles/hbm_traffic.json,
     written by profiles/summarize_traffic.py from the FETCH_SIZE / WRITE_SIZE runs of this same
@@ -212,6 +224,14 @@ def main():
             "node_tests_per_ray": round(counters["node_tests"] / counters["rays"], 2),
             "sphere_tests_per_ray": round(counters["sphere_tests"] / counters["rays"], 2),
         }
+        # What does bound the loop: vector-instruction issue.  Wave-instructions per launch from the
+        # committed PMC pass, 2 cycles each on a SIMD, over the SIMD-cycles of the launch measured here.
+        valu = profiled(world, args.spp, "valu_insts_per_launch")
+        if valu:
+            prop = torch.cuda.get_device_properties(dev)
+            simd_cycles = prop.multi_processor_count * 4 * avg_kernel_ms * 1e-3 * SHADER_CLOCK_HZ
+            out["roofline"]["valu_issue_frac"] = round(2.0 * valu / simd_cycles, 3)
+            out["roofline"]["lane_utilisation"] = round(profiled(world, args.spp, "lane_utilisation") or 0.0, 3)
     ctx.close()
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -33,10 +33,28 @@ def per_dispatch(root, counter):
     return None
 
 
+def render_kernel(root, counter):
+    """Average per dispatch of the render kernel alone."""
+    for db_path in sorted(glob.glob(os.path.join(root, "*", "*_results.db"))):
+        cur = sqlite3.connect(db_path).cursor()
+        try:
+            rows = list(cur.execute(
+                "select sum(value) / count(distinct dispatch_id) from counters_collection "
+                "where counter_name = ? and kernel_name like ?", (counter, "%renderWavefront<true, false, false>%")))
+        except sqlite3.Error:
+            rows = []
+        if rows and rows[0][0] is not None:
+            return float(rows[0][0])
+    return None
+
+
 def main(root):
     rd, wr = per_dispatch(root, "FETCH_SIZE"), per_dispatch(root, "WRITE_SIZE")
+    valu, active, lanes = (render_kernel(root, c) for c in ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU"))
     out = {"source": os.path.basename(os.path.normpath(root)), "fetch_kb_per_launch": rd, "write_kb_per_launch": wr,
            "hbm_bytes_per_launch": None if rd is None or wr is None else int((2.0 * rd + wr) * 1024),
+           "valu_insts_per_launch": valu,
+           "lane_utilisation": None if not (active and lanes) else lanes / (64.0 * active),
            "workload": "bench.py default: cover scene 1920x1080, 64 spp, 1 GPU"}
     here = os.path.dirname(os.path.abspath(__file__))
     with open(os.path.join(here, "hbm_traffic.json"), "w") as f:
