@@ -279,48 +279,6 @@ struct Builder {
 
 }  // namespace
 
-// 16-byte form of the search structure (FlatScene::fast_q).  Every plane moves outwards by between
-// one and two steps (a step is 1/65533 of the scene's extent on that axis), which is far more than
-// the rounding error of the kernels' `step * (scale / d) + (lo / d - o / d)`, so the 16-byte boxes
-// contain the padded 32-byte ones and the walk stays conservative.
-static void quantiseFastStructure(FlatScene& f) {
-    f.fast_q.clear();
-    const size_t n = f.fast_nodes.size() / 8;
-    if (n == 0 || f.fast_refs.size() >= 0x7FFFFFFFu) return;
-    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (size_t e = 0; e < n; e++)
-        for (int k = 0; k < 3; k++) {
-            const double mn = f32(f.fast_nodes[e * 8 + 2 * k]), mx = f32(f.fast_nodes[e * 8 + 2 * k + 1]);
-            if (!(mn <= mx)) return;  // the inverted box of an empty world, or NaN: keep the 32-byte form only
-            lo[k] = std::min(lo[k], mn);
-            hi[k] = std::max(hi[k], mx);
-        }
-    for (int k = 0; k < 3; k++) {
-        if (!std::isfinite(lo[k]) || !std::isfinite(hi[k])) return;
-        float l = (float)lo[k];
-        if ((double)l > lo[k]) l = std::nextafter(l, -INFINITY);
-        double step = (hi[k] - (double)l) / 65533.0;
-        float sc = (float)step;
-        if ((double)sc < step) sc = std::nextafter(sc, INFINITY);
-        if (!(sc > 0.0f)) sc = 1.0f;
-        f.q_lo[k] = l;
-        f.q_scale[k] = sc;
-    }
-    f.fast_q.resize(n * 4);
-    for (size_t e = 0; e < n; e++) {
-        for (int k = 0; k < 3; k++) {
-            const double mn = f32(f.fast_nodes[e * 8 + 2 * k]), mx = f32(f.fast_nodes[e * 8 + 2 * k + 1]);
-            const double l = f.q_lo[k], sc = f.q_scale[k];
-            long long a = (long long)std::floor((mn - l) / sc) - 1, b = (long long)std::ceil((mx - l) / sc) + 1;
-            a = std::max(0ll, std::min(65535ll, a));
-            b = std::max(0ll, std::min(65535ll, b));
-            f.fast_q[e * 4 + k] = (uint32_t)a | ((uint32_t)b << 16);
-        }
-        const uint32_t skip = f.fast_nodes[e * 8 + 6], first = f.fast_nodes[e * 8 + 7];
-        f.fast_q[e * 4 + 3] = first != 0xFFFFFFFFu ? (0x80000000u | first) : skip;
-    }
-}
-
 void Scene::buildFastStructure() {
     FlatScene& f = flat;
     f.fast_stale = false;
@@ -424,7 +382,6 @@ void Scene::buildFastStructure() {
         // says, the walk ends without a hit)
         const float mn[3] = {1.0f, 1.0f, 1.0f}, mx[3] = {-1.0f, -1.0f, -1.0f};
         Builder{prims, f.fast_nodes, f.fast_refs}.newEntry(mn, mx);
-        f.fast_q.clear();
         return;
     }
     Builder bld{prims, f.fast_nodes, f.fast_refs};
@@ -433,7 +390,6 @@ void Scene::buildFastStructure() {
     if (const char* e = std::getenv("RT_FAST_COLLAPSE")) bld.collapse = (float)std::atof(e);
     for (int k = 0; k < 3; k++) bld.eye[k] = camera.origin[k];
     bld.run();
-    quantiseFastStructure(f);
 }
 
 }  // namespace rt

@@ -67,12 +67,6 @@ struct FlatScene {
     // through `nodes` in the reference's order.
     std::vector<uint32_t> fast_nodes;   // 8 words per entry: {min.x, max.x, min.y, max.y, min.z, max.z, skip, first_ref}
     std::vector<uint32_t> fast_refs;    // leaf references, as `prim_refs`
-    // The same entries in 16 bytes, for scenes whose tables are read from global memory: planes as
-    // 16-bit steps of q_scale from q_lo, rounded outwards (word k = min | max << 16 of axis k), and one
-    // link word: bit 31 set = leaf, low bits = start of its leaf run (a leaf's skip is entry + 1);
-    // clear = skip.  Empty when the scene does not allow it (see buildFastStructure).
-    std::vector<uint32_t> fast_q;
-    float q_lo[3] = {0, 0, 0}, q_scale[3] = {1, 1, 1};
     std::vector<int32_t> sphere_ord;    // sphere id   -> position in prim_refs (reference visit order)
     std::vector<int32_t> tri_ord;       // triangle id -> position in prim_refs
     std::vector<int32_t> prim_guard;    // position in prim_refs -> innermost box-tested entry of `nodes` above it, or -1

@@ -128,7 +128,7 @@ rt::RenderArgs makeArgs(rt_context* ctx, int first_sample, int n_samples, int ma
     a.first_sample = first_sample;
     a.n_samples = n_samples;
     a.max_depth = max_depth;
-    a.lds_bytes = ctx->dsc.q_mode == 2 ? (int)rt::ldsCompactBytes(ctx->dsc) : (int)ctx->lds_need;
+    a.lds_bytes = (int)ctx->lds_need;
     a.knob[2] = ctx->lds_refs ? 1 : 0;
     return a;
 }
@@ -502,11 +502,6 @@ int rt_upload_scene(rt_context* ctx, rt_scene* s) {
     std::memcpy(fastNodes.data(), sc.flat.fast_nodes.data(), sc.flat.fast_nodes.size() * 4);
     if ((rc = devUpload(ctx, fastNodes, &d.fast_nodes))) return rc;
     if ((rc = devUpload(ctx, sc.flat.fast_refs, &d.fast_refs))) return rc;
-    std::vector<uint4> fastQ(sc.flat.fast_q.size() / 4);
-    std::memcpy(fastQ.data(), sc.flat.fast_q.data(), sc.flat.fast_q.size() * 4);
-    if ((rc = devUpload(ctx, fastQ, &d.fast_q))) return rc;
-    std::memcpy(d.q_lo, sc.flat.q_lo, sizeof(d.q_lo));
-    std::memcpy(d.q_scale, sc.flat.q_scale, sizeof(d.q_scale));
     if ((rc = devUpload(ctx, sc.flat.sphere_ord, &d.sphere_ord))) return rc;
     if ((rc = devUpload(ctx, sc.flat.tri_ord, &d.tri_ord))) return rc;
     if ((rc = devUpload(ctx, sc.flat.prim_guard, &d.prim_guard))) return rc;
@@ -545,15 +540,6 @@ int rt_upload_scene(rt_context* ctx, rt_scene* s) {
         ctx->lds_refs = all <= kLdsThreeGroups || (part > kLdsThreeGroups && all <= kMaxLdsScene);
     ctx->lds_need = ctx->lds_refs ? all : part;
     ctx->use_lds = ctx->lds_need <= kMaxLdsScene && ldsMode != 0;
-    // Tables in global memory: the persistent kernel then walks the 16-byte entries (half the bytes per
-    // box step), from LDS when they and the leaf references fit beside two other workgroups.
-    // RT_COMPACT overrides: 0 = 32-byte entries, 1 = 16-byte from global memory, 2 = staged.
-    ctx->dsc.q_mode = 0;
-    if (!ctx->use_lds && !sc.flat.fast_q.empty()) {
-        const int want = envInt("RT_COMPACT", -1);
-        const bool fits = rt::ldsCompactBytes(d) <= kLdsThreeGroups;
-        ctx->dsc.q_mode = want == 0 ? 0 : (want == 1 ? 1 : (want == 2 ? (fits ? 2 : 1) : (fits ? 2 : 1)));
-    }
     ctx->scene_loaded = true;
     return RT_OK;
 }

@@ -14,12 +14,6 @@ struct DevScene {
     // search structure traversed first (same entry format, padded boxes) and its guard data
     const float4* fast_nodes;
     const uint32_t* fast_refs;
-    // 16-byte form of the same entries for the persistent kernel when the tables stay in global
-    // memory: {x, y, z} = min | max << 16 in steps of q_scale from q_lo, w = leaf flag | link.
-    // q_mode: 0 not used, 1 read from global memory, 2 staged into LDS together with fast_refs.
-    const uint4* fast_q;
-    float q_lo[3], q_scale[3];
-    int q_mode;
     const int* sphere_ord;    // sphere id   -> position in prim_refs (the reference's visit order)
     const int* tri_ord;       // triangle id -> position in prim_refs
     const int* prim_guard;    // position in prim_refs -> innermost box-tested entry of `nodes` above it, or -1
@@ -79,12 +73,6 @@ inline size_t ldsSceneBytes(const DevScene& s, bool with_reference_arrays = true
         n += al((size_t)s.n_nodes * 32) + al((size_t)s.n_prim_refs * 4) + al((size_t)s.n_prim_refs * 4) +
              al((size_t)s.n_nodes * 4);
     return n;
-}
-
-// LDS bytes of the 16-byte search structure plus its leaf references (q_mode 2).
-inline size_t ldsCompactBytes(const DevScene& s) {
-    auto al = [](size_t x) { return (x + 15) & ~size_t(15); };
-    return al((size_t)s.n_fast_nodes * 16) + al((size_t)s.n_fast_refs * 4);
 }
 
 }  // namespace rt

@@ -704,29 +704,15 @@ __device__ __forceinline__ int popc64(unsigned long long m) {
 // TIME (diagnostic): instead of path counters, each wave adds up its clock ticks per operation
 // -- box bursts, primitive runs, SHADE, NEWPATH, reference-order box steps, and everything else
 // (votes, loop overhead) -- into the scheduling-statistics slots.
-// Q: the search structure is walked in its 16-byte form (DevScene::fast_q), 1 = from global memory,
-// 2 = staged into LDS together with its leaf references; only without LDS (the other tables in
-// global memory).
-template <bool LDS, bool COUNT, bool TIME = false, int Q = 0>
+template <bool LDS, bool COUNT, bool TIME = false>
 __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
-    static_assert(!(LDS && Q != 0), "the 16-byte entries are for scenes whose tables stay in global memory");
     const DevScene& sc = a.sc;
     fillCounterLut();
     SceneView sv;
-    const uint4* qnodes = sc.fast_q;
     if (LDS) {
         sv = stageScene(sc, a.knob[2] != 0);
     } else {
         sv = globalView(sc);
-        if (Q == 2) {
-            uint4* dst = reinterpret_cast<uint4*>(rt_lds);
-            for (int i = threadIdx.x; i < sc.n_fast_nodes; i += blockDim.x) dst[i] = sc.fast_q[i];
-            uint32_t* refs = reinterpret_cast<uint32_t*>(dst + sc.n_fast_nodes);
-            for (int i = threadIdx.x; i < sc.n_fast_refs; i += blockDim.x) refs[i] = sc.fast_refs[i];
-            __syncthreads();
-            qnodes = dst;
-            sv.frefs = refs;
-        }
     }
     const int lane = threadIdx.x & 63;
     const int nNodesRef = sc.n_nodes, nNodesFast = sc.n_fast_nodes;
@@ -746,9 +732,6 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
     Ray r{{0.f, 0.f, 0.f}, {0.f, 0.f, 1.f}};
     float invx = 0.f, invy = 0.f, invz = 0.f, aa = 1.f;
     float nox = 0.f, noy = 0.f, noz = 0.f;  // -origin / direction, for the search structure's box test
-    // Q: plane = q_lo + step * q_scale, so distance = step * (q_scale / d) + (q_lo / d - origin / d):
-    // the first factor here, the second term in nox..noz
-    float qax = 0.f, qay = 0.f, qaz = 0.f;
     Hit h{0.f, kNoHit, 0.f, 0.f};
     // 0: the lane walks the search structure; 1: it walks the reference-order array (diagnostic
     // setting, zero direction component, or a re-trace after a failed guard test / NaN distance)
@@ -785,14 +768,6 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
         nox = -(r.o.x * invx);
         noy = -(r.o.y * invy);
         noz = -(r.o.z * invz);
-        if (Q != 0) {
-            qax = sc.q_scale[0] * invx;
-            qay = sc.q_scale[1] * invy;
-            qaz = sc.q_scale[2] * invz;
-            nox = sc.q_lo[0] * invx + nox;
-            noy = sc.q_lo[1] * invy + noy;
-            noz = sc.q_lo[2] * invz + noz;
-        }
         mode = (sc.force_ref || !fastTestUsable(invx, invy, invz, nox, noy, noz)) ? 1 : 0;
         op = mode ? OP_REFBOX : OP_BOX;
         if (COUNT) st.v[C_RAYS]++;
@@ -859,22 +834,7 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
                             schedExec[5] += 1;
                             schedLanes[5] += popc64(__ballot(op == OP_BOX));
                         }
-                        if (Q != 0) {
-                            if (op == OP_BOX) {
-                                const uint4 e = qnodes[idx];
-                                if (COUNT) st.v[C_NODE]++;
-                                const float4 n0 = make_float4((float)(e.x & 0xFFFFu), (float)(e.x >> 16),
-                                                              (float)(e.y & 0xFFFFu), (float)(e.y >> 16));
-                                const float4 n1 = make_float4((float)(e.z & 0xFFFFu), (float)(e.z >> 16), 0.f, 0.f);
-                                const bool pass = slabPassFast(n0, n1, qax, qay, qaz, nox, noy, noz, h.t);
-                                const bool leaf = (int)e.w < 0;
-                                const int link = (int)(e.w & 0x7FFFFFFFu);
-                                idx = (pass | leaf) ? idx + 1 : link;
-                                p = link;  // a leaf's link is the start of its run
-                                const int onward = idx >= nNodesFast ? afterWalk() : OP_BOX;
-                                op = (pass & leaf) ? OP_PRIM : onward;
-                            }
-                        } else if (op == OP_BOX) {
+                        if (op == OP_BOX) {
                             const float4 n0 = sv.fnodes[2 * idx], n1 = sv.fnodes[2 * idx + 1];
                             const int first = (int)fbits(n1.w);
                             if (COUNT) st.v[C_NODE]++;
@@ -1212,12 +1172,12 @@ __global__ void __launch_bounds__(256) resolveKernel(const float4* payloads, siz
 }
 
 // ------------------------------------------------------------------ launch wrappers
-template <bool LDS, bool COUNT, bool TIME = false, int Q = 0>
+template <bool LDS, bool COUNT, bool TIME = false>
 static hipError_t launchWavefrontT(const RenderArgs& a, int blocks, int threads, size_t shmem, hipStream_t stream) {
-    if (LDS || Q == 2)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(renderWavefront<LDS, COUNT, TIME, Q>),
+    if (LDS)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(renderWavefront<LDS, COUNT, TIME>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    renderWavefront<LDS, COUNT, TIME, Q><<<blocks, threads, shmem, stream>>>(a);
+    renderWavefront<LDS, COUNT, TIME><<<blocks, threads, shmem, stream>>>(a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const int nSlots = a.n_local_tiles * 64;
@@ -1230,14 +1190,6 @@ hipError_t launchWavefront(const RenderArgs& a, bool lds, bool count, int blocks
     if (count && a.timing)
         return lds ? launchWavefrontT<true, false, true>(a, blocks, threads, shmem, stream)
                    : launchWavefrontT<false, false, true>(a, blocks, threads, 0, stream);
-    if (!lds && a.sc.q_mode == 2) {
-        shmem = (size_t)a.lds_bytes;
-        return count ? launchWavefrontT<false, true, false, 2>(a, blocks, threads, shmem, stream)
-                     : launchWavefrontT<false, false, false, 2>(a, blocks, threads, shmem, stream);
-    }
-    if (!lds && a.sc.q_mode == 1)
-        return count ? launchWavefrontT<false, true, false, 1>(a, blocks, threads, 0, stream)
-                     : launchWavefrontT<false, false, false, 1>(a, blocks, threads, 0, stream);
     if (lds) return count ? launchWavefrontT<true, true>(a, blocks, threads, shmem, stream)
                           : launchWavefrontT<true, false>(a, blocks, threads, shmem, stream);
     return count ? launchWavefrontT<false, true>(a, blocks, threads, 0, stream)
