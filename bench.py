@@ -9,7 +9,7 @@ pixel (+ for N > 1 one all-gather of the rank payloads over RCCL and the device 
 row-major RGBA32F frame).  N GPUs shard the 8x8-pixel tiles of the same 1080p frame and each
 renders 64*N samples per pixel of its tiles, so per-GPU work is fixed ("weak" scaling) and the
 gathered frame is a 64*N-spp image.  The scene lives in device memory before timing starts; the
-frame stays in device memory (the PCIe-inclusive figure is in DESIGN.md).
+frame stays in device memory (copying it to the host as RGBA8 adds 8.3 MB over PCIe, about 0.2 ms).
 
 Prints ONE JSON line on rank 0.
 """

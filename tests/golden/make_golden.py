@@ -3,7 +3,7 @@
 The reference holds no tests, fixtures or known-answer vectors for this path and cannot be
 built here (its math library, glm, is an empty submodule), so these files are outputs of the
 oracle restatement, committed to pin it against regressions.  `anchors.json` additionally
-records values taken from the structural survey of the reference (scene census,
+records values taken from a structural survey of the reference's sources (scene census,
 first grid sphere, and two whole-image checksums of the reference's own sources rendering
 200x112 at 1 spp), which the oracle reproduces.
 
@@ -90,7 +90,7 @@ def main():
 
     out["oracle_checksums"] = img_sums
     out["survey_recorded"] = {
-        "comment": "values recorded in SURVEY.md from the survey's probe of the reference sources",
+        "comment": "values recorded by a probe of the reference sources (g++ build, sequential mt19937 stream)",
         "n_spheres": 488, "n_lambertian": 392, "n_metal": 71, "n_dielectric": 25,
         "first_draw": 0.81472367,
         "first_grid_sphere": {"kind": 1, "center": [-10.1847878, 0.2, -10.8780708],
