@@ -24,6 +24,8 @@ from rtiow_amd import scenes  # noqa: E402
 def make_builder(seed):
     rr = np.random.RandomState(seed)
     n_sph = int(rr.choice([0, 1, 3, 20, 120]))
+    if seed % 10 == 0:
+        n_sph = int(rr.choice([3000, 9000]))  # too many for LDS: the tables are read from global memory
     n_tri = int(rr.choice([0, 1, 7, 40]))
     n_mesh = int(rr.choice([0, 0, 1, 2]))
     if n_sph + n_tri + n_mesh == 0:
@@ -46,7 +48,14 @@ def make_builder(seed):
     inside = rr.rand() < 0.5
     lookfrom = ((rr.rand(3) * extent) if inside else (rr.rand(3) * 4 - 1.5) * extent).astype(np.float32)
     lookat = (rr.rand(3) * extent).astype(np.float32)
+    if seed % 7 == 0:
+        # looking straight along an axis from a point with equal coordinates: direction components that
+        # are exactly zero for the centre rays (the reference-order walk takes those)
+        lookfrom = np.array([extent * 0.5, extent * 0.5, -extent], np.float32)
+        lookat = np.array([extent * 0.5, extent * 0.5, extent], np.float32)
     aperture = float(rr.choice([0.0, 0.1 * extent / 30.0]))
+    if seed % 7 == 0:
+        aperture = 0.0
     vfov = float(rr.choice([20.0, 40.0, 90.0]))
     bg = tuple(float(x) for x in rr.choice([0.0, 0.7, 1.0], 3))
     tex_seed = int(rr.randint(1 << 20))
