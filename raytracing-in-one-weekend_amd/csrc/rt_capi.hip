@@ -160,8 +160,6 @@ int launch(rt_context* ctx, rt::RenderArgs& a, bool count) {
     a.knob[1] = envInt("RT_SHADE_MIN", 32);
     a.knob[3] = std::max(1, envInt("RT_PRIM_KEEP", 16));
     a.timing = envInt("RT_TIMING", 0);
-    a.knob[4] = envInt("RT_PHASE_EXIT", 0);
-    a.knob[5] = envInt("RT_X5", 0);
     int wfThreads = envInt("RT_THREADS", 512);
     if (wfThreads < 64 || wfThreads > WF_MAX_THREADS || wfThreads % 64 != 0) wfThreads = 512;
     const int wfWaves = wfThreads / 64;

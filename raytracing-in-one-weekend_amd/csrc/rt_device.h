@@ -46,7 +46,7 @@ struct RenderArgs {
     int rank, world;
     int first_sample, n_samples, max_depth;
     int lds_bytes;
-    int knob[6];  // scheduling thresholds of the wavefront loop (never affect results)
+    int knob[4];  // scheduling thresholds of the wavefront loop (never affect results)
     int timing;  // counting launches collect per-operation clock ticks instead (diagnostic)
     // per-sample radiance of the launch: colors[(sample - first_sample) * n_slots + pixel slot],
     // added to the accumulation buffer in sample order by accumulateColors()

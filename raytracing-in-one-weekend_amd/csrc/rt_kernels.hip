@@ -899,8 +899,7 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
                 const int nPrim = popc64(__ballot(op == OP_PRIM));
                 const int others = total - nBox - nPrim;
                 const int best = nBox > nPrim ? nBox : nPrim;
-                const int pe = a.knob[4];
-                if (best == 0 || others >= shadeMin || (pe == 0 ? best < others : (pe == 1 ? false : (pe == 2 ? 2 * best < others : best < 2 * others)))) break;
+                if (best == 0 || others >= shadeMin || best < others) break;
                 cur = nBox >= nPrim ? OP_BOX : OP_PRIM;
                 if (COUNT) {
                     schedExec[cur] += 1;
