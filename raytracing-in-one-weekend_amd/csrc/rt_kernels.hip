@@ -698,11 +698,6 @@ __device__ __forceinline__ int popc64(unsigned long long m) {
 // 512-thread workgroups, three per CU = 6 waves per SIMD (80 registers per lane, a few cold values
 // spilled).  Measured on the cover scene: 4 waves per SIMD 37.6 ms, 6 waves 33.1 ms, 8 waves
 // (64 registers, heavy spilling) 60 ms.
-// 1: the scheduling thresholds come from the launch arguments (RT_BOX_KEEP, RT_SHADE_MIN, RT_PRIM_KEEP)
-// instead of being compile-time constants
-#ifndef WF_TUNABLE
-#define WF_TUNABLE 0
-#endif
 #ifndef WF_BOUNDS
 #define WF_BOUNDS 512, 6
 #endif
@@ -723,8 +718,8 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
     const int nNodesRef = sc.n_nodes, nNodesFast = sc.n_fast_nodes;
     const int nTiles = a.n_local_tiles;
     const unsigned int nChunks = (unsigned int)nTiles * (unsigned int)a.n_samples;  // 64 units each
-    const int boxKeep = WF_TUNABLE ? a.knob[0] : 8;    // keep running BOX steps while at least this many lanes want one
-    const int shadeMin = WF_TUNABLE ? a.knob[1] : 32;   // run SHADE / NEWPATH early once this many lanes wait for it
+    const int boxKeep = a.knob[0];    // keep running BOX steps while at least this many lanes want one
+    const int shadeMin = a.knob[1];   // run SHADE / NEWPATH early once this many lanes wait for it
     Stats st;
     if (COUNT)
         for (int i = 0; i < kNumStats; i++) st.v[i] = 0;
@@ -891,7 +886,7 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
                     if (LDS) {
                         // go on through the leaf runs while this many lanes have more (with the tables in
                         // global memory the plain single step measured faster: 407 vs 448 ms on Cornell + vase)
-                        const int primKeep = WF_TUNABLE ? a.knob[3] : 16;
+                        const int primKeep = a.knob[3];
                         do {
                             primStep();
                         } while (popc64(__ballot(op == OP_PRIM)) >= primKeep);
