@@ -418,6 +418,14 @@ __device__ __forceinline__ V3 textureAt(const DevScene& sc, int tex, float u, fl
     return {sc.lut[px & 255u], sc.lut[(px >> 8) & 255u], sc.lut[(px >> 16) & 255u]};
 }
 
+// vecNearZero, R/src/Core/RTWeekend.cpp:39-43: every |component| < 1e-8, compared as doubles there.
+// The float nearest to 1e-8 lies below it (0x322BCC77 = 9.99999994e-9) and the next float lies above,
+// so for a float x, (double)x < 1e-8 holds exactly when x <= that float.
+__device__ __forceinline__ bool nearZero(V3 v) {
+    const float lim = __uint_as_float(0x322BCC77u);
+    return fabsf(v.x) <= lim && fabsf(v.y) <= lim && fabsf(v.z) <= lim;
+}
+
 // Material::scatter for the five material kinds (R/src/Material/Material.h:22-160).
 // Returns true if the path continues with `out` and `atten`; false ends it with `emit`.
 template <bool COUNT>
@@ -437,8 +445,7 @@ __device__ __forceinline__ bool scatter(const DevScene& sc, const SceneView& sv,
     if (kind == 0) {  // Lambertian, Material.h:22-36
         if (COUNT) st->v[C_LAMB]++;
         V3 dir = s.n + normalize(ball);
-        // vecNearZero, R/src/Core/RTWeekend.cpp:39-43 (threshold 1e-8 as a double)
-        if (((double)fabsf(dir.x) < 1e-8) && ((double)fabsf(dir.y) < 1e-8) && ((double)fabsf(dir.z) < 1e-8)) dir = s.n;
+        if (nearZero(dir)) dir = s.n;
         out.d = dir;
         atten = {m0.x, m0.y, m0.z};
         return true;
@@ -496,7 +503,7 @@ __device__ __forceinline__ bool scatter(const DevScene& sc, const SceneView& sv,
         return dot(out.d, s.n) > 0;
     }
     V3 dir = s.n + normalize(ball);
-    if (((double)fabsf(dir.x) < 1e-8) && ((double)fabsf(dir.y) < 1e-8) && ((double)fabsf(dir.z) < 1e-8)) dir = s.n;
+    if (nearZero(dir)) dir = s.n;
     out.d = dir;
     return true;
 }
