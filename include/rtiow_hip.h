@@ -143,6 +143,13 @@ int rt_scene_get_flat(const rt_scene* s, uint32_t* nodes8, uint32_t* prim_refs, 
  * first_ref = 0xFFFFFFFF for an entry without a leaf run.  refs: as prim_refs.  Sizes come back in
  * n_entries / n_refs; either array may be NULL (call once for the sizes, once for the data). */
 int rt_scene_get_search_structure(const rt_scene* s, int* n_entries, uint32_t* entries8, int* n_refs, uint32_t* refs);
+/* Scenes too large for LDS (and up to 2 M entries) carry the same entries eight times, each copy
+ * with the children of every entry ordered near-to-far for one sign pattern of the ray direction
+ * (copy k: bit a of k set = component a negative); a ray walks the copy for its signs.  A copy has
+ * `stride` entries (the last one a box no ray passes); links index the whole array and
+ * 8 * stride means "walk over"; leaf runs are the refs of rt_scene_get_search_structure.
+ * stride comes back 0 when the scene has no such copies; entries8 may be NULL. */
+int rt_scene_get_search_structure_octants(const rt_scene* s, int* stride, uint32_t* entries8);
 
 /* ------------------------------------------------------------------ device */
 

@@ -70,6 +70,7 @@ SYMBOLS = {
     "rt_scene_flatten": (_I, [_VP, C.POINTER(FlatInfo)]),
     "rt_scene_get_flat": (_I, [_VP] + [_VP] * 10),
     "rt_scene_get_search_structure": (_I, [_VP, C.POINTER(_I), _VP, C.POINTER(_I), _VP]),
+    "rt_scene_get_search_structure_octants": (_I, [_VP, C.POINTER(_I), _VP]),
     "rt_device_count": (_I, []),
     "rt_create": (_I, [_I, C.POINTER(_VP)]),
     "rt_destroy": (None, [_VP]),
@@ -246,6 +247,17 @@ class Scene:
         refs = np.zeros(nr.value, np.uint32)
         _check(lib.rt_scene_get_search_structure(self.h, None, _p(entries), None, _p(refs)))
         return entries, refs
+
+    def search_structure_octants(self):
+        """The eight direction-ordered copies: (stride, entries [8 * stride, 8] uint32), or (0, None)."""
+        self.flatten()
+        stride = C.c_int(0)
+        _check(lib.rt_scene_get_search_structure_octants(self.h, C.byref(stride), None))
+        if stride.value == 0:
+            return 0, None
+        entries = np.zeros((8 * stride.value, 8), np.uint32)
+        _check(lib.rt_scene_get_search_structure_octants(self.h, None, _p(entries)))
+        return stride.value, entries
 
 
 def device_count():

@@ -67,6 +67,13 @@ struct FlatScene {
     // through `nodes` in the reference's order.
     std::vector<uint32_t> fast_nodes;   // 8 words per entry: {min.x, max.x, min.y, max.y, min.z, max.z, skip, first_ref}
     std::vector<uint32_t> fast_refs;    // leaf references, as `prim_refs`
+    // For scenes too large for LDS: the same entries eight times over, each copy with the children of
+    // every entry ordered near-to-far for one sign pattern of the ray direction (copy k: bit a of k
+    // set = direction component a negative).  A copy has fast_oct_stride entries, the last one a box
+    // no ray passes; links are indices into the whole array, "walk over" = 8 * fast_oct_stride.
+    // The leaf runs are shared (fast_refs).  Empty for scenes that fit LDS.
+    std::vector<uint32_t> fast_oct;
+    int fast_oct_stride = 0;
     std::vector<int32_t> sphere_ord;    // sphere id   -> position in prim_refs (reference visit order)
     std::vector<int32_t> tri_ord;       // triangle id -> position in prim_refs
     std::vector<int32_t> prim_guard;    // position in prim_refs -> innermost box-tested entry of `nodes` above it, or -1

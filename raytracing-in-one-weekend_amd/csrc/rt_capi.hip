@@ -366,6 +366,15 @@ int rt_scene_get_search_structure(const rt_scene* s, int* n_entries, uint32_t* e
     return RT_OK;
 }
 
+int rt_scene_get_search_structure_octants(const rt_scene* s, int* stride, uint32_t* entries8) {
+    if (!s) return fail(RT_ERR_INVALID, "null scene");
+    const rt::Scene& sc = s->sc;
+    if (!sc.flat.valid) return fail(RT_ERR_STATE, "rt_scene_flatten() has not been called");
+    if (stride) *stride = sc.flat.fast_oct_stride;
+    if (entries8 && !sc.flat.fast_oct.empty()) std::memcpy(entries8, sc.flat.fast_oct.data(), sc.flat.fast_oct.size() * 4);
+    return RT_OK;
+}
+
 // ------------------------------------------------------------------ device
 int rt_device_count(void) {
     int n = 0;
@@ -498,9 +507,26 @@ int rt_upload_scene(rt_context* ctx, rt_scene* s) {
     std::memcpy(nodes.data(), sc.flat.nodes.data(), sc.flat.nodes.size() * 4);
     if ((rc = devUpload(ctx, nodes, &d.nodes))) return rc;
     if ((rc = devUpload(ctx, sc.flat.prim_refs, &d.prim_refs))) return rc;
-    std::vector<float4> fastNodes(sc.flat.fast_nodes.size() / 4);
-    std::memcpy(fastNodes.data(), sc.flat.fast_nodes.data(), sc.flat.fast_nodes.size() * 4);
+    // Scenes whose tables stay in global memory walk the direction-ordered copies of the search
+    // structure (same decision as for LDS below, taken here on the counts alone).
+    bool octants = false;
+    {
+        rt::DevScene probe{};
+        probe.n_nodes = nNodes;
+        probe.n_prim_refs = (int)sc.flat.prim_refs.size();
+        probe.n_fast_nodes = (int)(sc.flat.fast_nodes.size() / 8);
+        probe.n_fast_refs = (int)sc.flat.fast_refs.size();
+        probe.n_spheres = (int)sc.spheres.size();
+        probe.n_tris = (int)sc.triangles.size();
+        probe.n_mats = (int)sc.materials.size();
+        const bool fitsLds = rt::ldsSceneBytes(probe, false) <= kMaxLdsScene && envInt("RT_LDS", -1) != 0;
+        octants = !fitsLds && sc.flat.fast_oct_stride > 0 && envInt("RT_OCTANTS", 1) != 0;
+    }
+    const std::vector<uint32_t>& fastSrc = octants ? sc.flat.fast_oct : sc.flat.fast_nodes;
+    std::vector<float4> fastNodes(fastSrc.size() / 4);
+    std::memcpy(fastNodes.data(), fastSrc.data(), fastSrc.size() * 4);
     if ((rc = devUpload(ctx, fastNodes, &d.fast_nodes))) return rc;
+    d.fast_oct_stride = octants ? sc.flat.fast_oct_stride : 0;
     if ((rc = devUpload(ctx, sc.flat.fast_refs, &d.fast_refs))) return rc;
     if ((rc = devUpload(ctx, sc.flat.sphere_ord, &d.sphere_ord))) return rc;
     if ((rc = devUpload(ctx, sc.flat.tri_ord, &d.tri_ord))) return rc;
@@ -517,7 +543,7 @@ int rt_upload_scene(rt_context* ctx, rt_scene* s) {
     if ((rc = devUpload(ctx, lut, &d.lut))) return rc;
     d.n_nodes = nNodes;
     d.n_prim_refs = (int)sc.flat.prim_refs.size();
-    d.n_fast_nodes = (int)(sc.flat.fast_nodes.size() / 8);
+    d.n_fast_nodes = (int)(fastSrc.size() / 8);
     d.n_fast_refs = (int)sc.flat.fast_refs.size();
     d.force_ref = (ctx->force_ref || hugeCoords) ? 1 : 0;
     ctx->huge_coords = hugeCoords;

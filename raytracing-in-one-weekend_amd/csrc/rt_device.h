@@ -29,6 +29,7 @@ struct DevScene {
     const int4* tex_desc;     // {first texel, width, height, 0}
     const float* lut;         // 256-entry 8-bit -> float map
     int n_nodes, n_prim_refs, n_fast_nodes, n_fast_refs, n_spheres, n_tris, n_mats;
+    int fast_oct_stride;      // > 0: fast_nodes holds 8 direction-ordered copies of this many entries each
     int force_ref;            // 1: always walk `nodes` in the reference's order (diagnostics)
     float cam[22];            // origin, lowerLeftCorner, horizontal, vertical, u, v, w, lensRadius
     float bg[3];

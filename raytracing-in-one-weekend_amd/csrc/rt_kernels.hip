@@ -771,12 +771,14 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
         aa = dot(r.d, r.d);
         h.t = __builtin_inff();
         h.ref = kNoHit;
-        idx = 0;
+        // with direction-ordered copies of the search structure: the copy for this ray's signs
+        idx = LDS ? 0 : ((r.d.x < 0.0f ? 1 : 0) | (r.d.y < 0.0f ? 2 : 0) | (r.d.z < 0.0f ? 4 : 0)) * sc.fast_oct_stride;
         nox = -(r.o.x * invx);
         noy = -(r.o.y * invy);
         noz = -(r.o.z * invz);
         mode = (sc.force_ref || !fastTestUsable(invx, invy, invz, nox, noy, noz)) ? 1 : 0;
         op = mode ? OP_REFBOX : OP_BOX;
+        if (mode) idx = 0;  // the reference-order array has one order only
         if (COUNT) st.v[C_RAYS]++;
     };
     auto retraceInReferenceOrder = [&]() {

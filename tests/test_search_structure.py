@@ -159,3 +159,44 @@ def test_moved_eye_reorders_and_keeps_the_invariants(rt, scenes):
     e2, r2 = check_search_structure(s)
     assert e2.shape == e0.shape and not np.array_equal(e0, e2)
     assert np.array_equal(np.sort(r0 & ~np.uint32(LAST)), np.sort(r2 & ~np.uint32(LAST)))
+
+
+def test_direction_ordered_copies(rt, scenes):
+    """A scene too large for LDS carries eight copies of the entries, one per sign pattern of the ray
+    direction: same boxes and leaf runs as the plain structure, links inside the copy or "walk over",
+    and of two sibling subtrees the one that starts earlier along the copy's direction comes first."""
+    small = rt.Scene()
+    scenes.cover_scene(small, 640, 360)
+    assert small.search_structure_octants() == (0, None)
+
+    mesh = scenes.load_gltf_mesh(os.path.join(G, "brass_vase", "brass_vase_04_4k.gltf"))
+    tex = {"diffuse": scenes.noise_texture(16, 1), "roughness": scenes.noise_texture(16, 2), "normal": None}
+    s = rt.Scene()
+    scenes.cornell_mesh_scene(s, 640, 360, mesh, tex)
+    entries, refs = check_search_structure(s)
+    stride, oct_entries = s.search_structure_octants()
+    n = len(entries)
+    assert stride == n + 1 and oct_entries.shape == (8 * stride, 8)
+    total = 8 * stride
+    plain = {tuple(e[:6]) + (e[7],) for e in entries}
+    for k in range(8):
+        base = k * stride
+        c = oct_entries[base:base + stride]
+        # the same set of (box, leaf run) pairs, plus the closing entry
+        assert {tuple(e[:6]) + (e[7],) for e in c[:n]} == plain
+        last = c[n]
+        assert np.isinf(last[:2].view(np.float32)).all() and last[6] == total and last[7] == NONE
+        skip = c[:n, 6].astype(np.int64)
+        inside = (skip > base + np.arange(n)) & (skip <= base + n)
+        assert (inside | (skip == total)).all()
+        local = np.where(skip == total, n, skip - base)
+        stack = []
+        for e in range(n):      # forward links, nested subtrees, as in the plain structure
+            assert e < local[e] <= n
+            while stack and stack[-1] <= e:
+                stack.pop()
+            if stack:
+                assert local[e] <= stack[-1]
+            stack.append(local[e])
+        leaf = c[:n, 7] != NONE
+        assert (local[leaf] == np.nonzero(leaf)[0] + 1).all()
