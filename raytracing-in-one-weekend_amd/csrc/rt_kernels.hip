@@ -854,11 +854,14 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
                             op = (pass & (first >= 0)) ? OP_PRIM : onward;
                         }
                     };
-                    do {  // three steps per look at the lane count (1: 32.35 ms, 2: 31.75, 3: 31.6, 4: 31.7)
+                    int still;
+                    do {  // three steps per look at the lane count (1: 32.35 ms, 2: 31.75, 3: 31.6, 4: 31.7);
+                          // the look comes before the third step, whose execution hides its latency
                         boxStep();
                         boxStep();
+                        still = popc64(__ballot(op == OP_BOX));
                         boxStep();
-                    } while (popc64(__ballot(op == OP_BOX)) >= keep && keep > 0);
+                    } while (still >= keep && keep > 0);
                     lap(T_BOX);
                 } else {
                     auto primStep = [&]() {
