@@ -705,9 +705,6 @@ __device__ __forceinline__ int popc64(unsigned long long m) {
 // 512-thread workgroups, three per CU = 6 waves per SIMD (80 registers per lane, a few cold values
 // spilled).  Measured on the cover scene: 4 waves per SIMD 37.6 ms, 6 waves 33.1 ms, 8 waves
 // (64 registers, heavy spilling) 60 ms.
-#ifndef PHASE_PATTERN
-#define PHASE_PATTERN 0
-#endif
 #ifndef WF_BOUNDS
 #define WF_BOUNDS 512, 6
 #endif
@@ -910,30 +907,6 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
                     }
                     lap(T_PRIM);
                 }
-#if PHASE_PATTERN
-                // fixed pattern: after a box burst one primitive step for whoever waits, and back
-                if (cur == OP_BOX) {
-                    auto primOnce = [&]() {
-                        if (op == OP_PRIM) {
-                            const uint32_t ref = sv.frefs[p];
-                            bool bad = false;
-                            float t, u = 0.0f, v = 0.0f;
-                            if (mode == 0) {
-                                if (primRoot<COUNT>(sv, ref, r, aa, __builtin_inff(), t, u, v, &st)) {
-                                    bad = t != t;
-                                    if (!bad && (h.ref == kNoHit || t < h.t || (t == h.t && refOrder(sv, ref) > refOrder(sv, h.ref)))) {
-                                        h.t = t; h.ref = ref & ~kRefLast; h.bu = u; h.bv = v;
-                                    }
-                                }
-                                if (bad) retraceInReferenceOrder();
-                                else if (ref & kRefLast) op = idx >= nNodesFast ? afterWalk() : OP_BOX;
-                                else p += 1;
-                            }
-                        }
-                    };
-                    primOnce();
-                }
-#endif
                 nBox = popc64(__ballot(op == OP_BOX));
                 const int nPrim = popc64(__ballot(op == OP_PRIM));
                 const int others = total - nBox - nPrim;
