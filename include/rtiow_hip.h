@@ -69,6 +69,10 @@ int rt_scene_add_material(rt_scene* s, int kind, float r, float g, float b, floa
  * the 8-bit -> float map of stbi_loadf, R/vendor/stb_image/stb_image.h:1840-1861, is applied
  * by the library).  Returns the texture index. */
 int rt_scene_add_texture_rgb8(rt_scene* s, int width, int height, const uint8_t* rgb);
+/* The 256 floats the byte values 0..255 become when a texture is loaded: stbi_loadf's LDR -> float
+ * map (R/vendor/stb_image/stb_image.h:1840-1861, called from R/src/Material/Texture.h:11), which
+ * the kernels apply per channel when they sample.  Host only. */
+int rt_texture_lut256(float* out256);
 /* PBRMaterial(diffuse) + setRoughnessTexture + setNormalTexture (Material.h:119,162-163);
  * pass -1 for an absent texture.  Returns the material index. */
 int rt_scene_add_material_pbr(rt_scene* s, int tex_diffuse, int tex_roughness, int tex_normal);

@@ -1105,6 +1105,13 @@ void orc_texture_at(void* s, int tex, int n, const float* uv, float* rgb) {
         rgb[3 * i + 2] = c.z;
     }
 }
+// the 256-entry byte -> float table a Texture applies
+void orc_texture_lut(float* out256) {
+    const uint8_t px[3] = {0, 0, 0};
+    Texture t(1, 1, px);
+    for (int i = 0; i < 256; i++) out256[i] = t.lut[i];
+}
+
 void orc_write_color(int n, const float* sums3, int samplesPerPixel, uint8_t* rgba) {
     for (int i = 0; i < n; i++) writeColorBytes(vec3(sums3[3 * i], sums3[3 * i + 1], sums3[3 * i + 2]), samplesPerPixel, rgba + 4 * i);
 }

@@ -55,6 +55,7 @@ SYMBOLS = {
     "rt_scene_rng_floats": (_I, [_VP, _I, _VP]),
     "rt_scene_add_material": (_I, [_VP, _I, _F, _F, _F, _F]),
     "rt_scene_add_texture_rgb8": (_I, [_VP, _I, _I, _VP]),
+    "rt_texture_lut256": (_I, [_VP]),
     "rt_scene_add_material_pbr": (_I, [_VP, _I, _I, _I]),
     "rt_scene_add_sphere": (_I, [_VP, _F, _F, _F, _F, _I]),
     "rt_scene_add_triangle": (_I, [_VP, _VP, _VP, _VP, _I]),
@@ -258,6 +259,13 @@ class Scene:
         entries = np.zeros((8 * stride.value, 8), np.uint32)
         _check(lib.rt_scene_get_search_structure_octants(self.h, None, _p(entries)))
         return stride.value, entries
+
+
+def texture_lut():
+    """The byte -> float map applied to texture channels (stbi_loadf's)."""
+    out = np.zeros(256, np.float32)
+    _check(lib.rt_texture_lut256(_p(out)))
+    return out
 
 
 def device_count():

@@ -228,6 +228,14 @@ int rt_scene_add_texture_rgb8(rt_scene* s, int width, int height, const uint8_t*
     if (!s || width <= 0 || height <= 0 || !rgb) return fail(RT_ERR_INVALID, "bad texture");
     return s->sc.addTexture(width, height, rgb);
 }
+// stbi_loadf's 8-bit -> float map, stbi__ldr_to_hdr: (float)(pow(byte / 255.0f, gamma) * scale) with
+// the float globals gamma = 2.2f and scale = 1.0f (R/vendor/stb_image/stb_image.h:1553-1554,1840-1861).
+// The reference compiles that file as C++, where pow(float, float) is the float overload.
+int rt_texture_lut256(float* out256) {
+    if (!out256) return fail(RT_ERR_INVALID, "null output pointer");
+    for (int i = 0; i < 256; i++) out256[i] = (float)(std::pow(i / 255.0f, 2.2f) * 1.0f);
+    return RT_OK;
+}
 int rt_scene_add_material_pbr(rt_scene* s, int td, int tr, int tn) {
     if (!s) return fail(RT_ERR_INVALID, "null scene");
     const int nt = (int)s->sc.textures.size();
@@ -496,10 +504,8 @@ int rt_upload_scene(rt_context* ctx, rt_scene* s) {
         for (size_t p = 0; p < n; p++)
             texels[base + p] = (uint32_t)t.rgb[3 * p] | ((uint32_t)t.rgb[3 * p + 1] << 8) | ((uint32_t)t.rgb[3 * p + 2] << 16);
     }
-    // stbi_loadf's 8-bit -> float map: (float)(pow(byte / 255.0f, 2.2f) * 1.0f) with float operands
-    // (R/vendor/stb_image/stb_image.h:1553,1851), applied per channel at sampling time.
-    std::vector<float> lut(256);
-    for (int i = 0; i < 256; i++) lut[i] = (float)(std::pow(i / 255.0f, 2.2f) * 1.0f);
+    std::vector<float> lut(256);  // applied per channel at sampling time
+    rt_texture_lut256(lut.data());
 
     rt::DevScene d{};
     int rc;

@@ -54,6 +54,7 @@ def lib():
                                   C.c_float, C.c_uint32, C.c_uint32, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p,
                                   C.POINTER(C.c_uint32)]
         L.orc_texture_at.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_texture_lut.argtypes = [C.c_void_p]
         L.orc_write_color.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         L.orc_render.argtypes = [C.c_void_p] + [C.c_int] * 10 + [C.c_void_p, C.c_void_p, C.POINTER(OrcCounters)]
         _lib = L
@@ -195,6 +196,12 @@ class OracleScene:
 
 def hash_random(x, y, sample, counter):
     return lib().orc_hash_random(x, y, sample, counter)
+
+
+def texture_lut():
+    out = np.zeros(256, np.float32)
+    lib().orc_texture_lut(_p(out))
+    return out
 
 
 def write_color(sums3, spp):
