@@ -244,6 +244,10 @@ int rt_scatter_test(rt_context* ctx, int n, const int32_t* material, const float
                     const float* normal3, const int32_t* front_face, const float* uv2, const uint32_t* key4,
                     float* atten3, float* ray_out6, int32_t* alive, uint32_t* counter_out);
 
+/* Test hook: Dielectric::reflectance(cosine, refIdx) (R/src/Material/Material.h:90-95, Schlick's
+ * approximation with pow() in double) for n pairs, as the kernels evaluate it.  Host pointers; blocking. */
+int rt_reflectance_test(rt_context* ctx, int n, const float* cosine, const float* ref_idx, float* out);
+
 /* Path statistics of one counting pass over the owned pixels (same paths as rt_render):
  * samples, rays, node tests, sphere tests, triangle tests, hits, scatters by material kind
  * (lambertian, metal, dielectric, light, pbr), misses, depth cut-offs.  Node and primitive

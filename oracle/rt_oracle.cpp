@@ -547,7 +547,23 @@ struct BVHNode : Hittable {  // Bvh.h:13-100
                 right = objects[start];
             }
         } else {
-            std::sort(objects.begin() + start, objects.begin() + end, comparator);
+            // std::sort(objects.begin() + start, objects.begin() + end, comparator)  (Bvh.h:46) with the
+            // comparator's key -- minimum[axis] of each operand's BoundingBox() -- computed once per
+            // element instead of twice per comparison.  std::sort's permutation is decided by the
+            // outcomes of its comparisons alone, and those are the same on the stored keys, so the
+            // resulting order is the one the reference's call produces (ties included).
+            {
+                std::vector<std::pair<float, HPtr>> keyed;
+                keyed.reserve(span);
+                for (size_t i = start; i < end; i++) {
+                    AABB b;
+                    objects[i]->BoundingBox(b);
+                    keyed.emplace_back(b.minimum[axis], std::move(objects[i]));
+                }
+                std::sort(keyed.begin(), keyed.end(),
+                          [](const std::pair<float, HPtr>& a, const std::pair<float, HPtr>& b) { return a.first < b.first; });
+                for (size_t i = start; i < end; i++) objects[i] = std::move(keyed[i - start].second);
+            }
             size_t mid = start + span / 2;
             if (maxDepth == 0) {
                 auto l = std::make_shared<HittableList>(), r = std::make_shared<HittableList>();
@@ -1105,6 +1121,11 @@ void orc_texture_at(void* s, int tex, int n, const float* uv, float* rgb) {
         rgb[3 * i + 2] = c.z;
     }
 }
+// Dielectric::reflectance for n (cosine, refraction ratio) pairs
+void orc_reflectance(int n, const float* cosine, const float* refIdx, float* out) {
+    for (int i = 0; i < n; i++) out[i] = Material::reflectance(cosine[i], refIdx[i]);
+}
+
 // the 256-entry byte -> float table a Texture applies
 void orc_texture_lut(float* out256) {
     const uint8_t px[3] = {0, 0, 0};

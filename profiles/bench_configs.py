@@ -95,31 +95,9 @@ def c5s(n_tris, w=1920, h=1080, spp=16, check=True):
     mesh = scenes.load_gltf_mesh(G)
     per = mesh["indices"].shape[0]
     copies = max(1, n_tris // per)
-    side = int(np.ceil(np.sqrt(copies)))
     tex = {"diffuse": scenes.noise_texture(1024, 1), "roughness": scenes.noise_texture(1024, 2), "normal": None}
-
-    def build(s):
-        s.cornell_box()
-        td, tr = s.add_texture(tex["diffuse"]), s.add_texture(tex["roughness"])
-        mat = s.add_pbr(td, tr, -1)
-        jit = s.rng_floats(2 * copies)          # grid jitter from the scene's own generator
-        # every copy is baked into one triangle list (the reference has no instancing)
-        pos, nrm, uv, idx = [], [], [], []
-        nv = mesh["positions"].shape[0]
-        for c in range(copies):
-            gx, gz = c % side, c // side
-            off = np.array([(gx + 0.3 * jit[2 * c]) * 0.09 - 0.045 * side, 0.0,
-                            (gz + 0.3 * jit[2 * c + 1]) * 0.09], np.float32)
-            pos.append(mesh["positions"] + off)
-            nrm.append(mesh["normals"])
-            uv.append(mesh["uvs"])
-            idx.append(mesh["indices"] + np.uint32(c * nv))
-        s.add_mesh(scenes.translate_scale((277.5, 100.0, 277.5), (500.0, 500.0, 500.0)), np.concatenate(pos),
-                   np.concatenate(idx), mat, normals=np.concatenate(nrm), uvs=np.concatenate(uv), max_depth=-1)
-        s.set_camera((278.0, 400.0, -800.0), (278.0, 150.0, 300.0), (0.0, 1.0, 0.0), 40.0, 1.0, 0.0, 10.0)
-        s.set_background((0.6, 0.7, 0.9))
-
-    run(f"C5 {copies} vases = {copies * per} triangles, {w}x{h}x{spp}", build, w, h, spp, [h // 2] if check else [], oracle_spp=1)
+    run(f"C5 {copies} vases = {copies * per} triangles, {w}x{h}x{spp}",
+        lambda s: scenes.instanced_mesh_scene(s, mesh, copies, tex), w, h, spp, [h // 2] if check else [], oracle_spp=1)
 
 
 def heartbeat():

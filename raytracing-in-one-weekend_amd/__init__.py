@@ -92,6 +92,7 @@ SYMBOLS = {
     "rt_resolve_gathered": (_I, [_VP, _VP, _I, _VP]),
     "rt_trace": (_I, [_VP, _I] + [_VP] * 7),
     "rt_scatter_test": (_I, [_VP, _I] + [_VP] * 11),
+    "rt_reflectance_test": (_I, [_VP, _I, _VP, _VP, _VP]),
     "rt_count": (_I, [_VP, _I, _I, _I, C.POINTER(Counters)]),
     "rt_sched_stats": (_I, [_VP, _VP]),
     "rt_last_render_ms": (_I, [_VP, C.POINTER(C.c_float)]),
@@ -360,6 +361,14 @@ class Context:
         _check(lib.rt_scatter_test(self.h, n, _p(material), _p(ray_in), _p(p), _p(normal), _p(front), _p(uv),
                                    _p(key4), _p(atten), _p(out), _p(alive), _p(cnt)))
         return atten, out, alive, cnt
+
+    def reflectance_test(self, cosine, ref_idx):
+        cosine, ref_idx = _f32(cosine), _f32(ref_idx)
+        if cosine.size != ref_idx.size:
+            raise ValueError("cosine and ref_idx must have the same length")
+        out = np.zeros(cosine.size, np.float32)
+        _check(lib.rt_reflectance_test(self.h, cosine.size, _p(cosine), _p(ref_idx), _p(out)))
+        return out
 
     def count(self, first_sample, n_samples, max_depth=50):
         c = Counters()

@@ -326,6 +326,7 @@ void Scene::buildFastStructure() {
     f.fast_refs.clear();
     f.fast_oct.clear();
     f.fast_oct_stride = 0;
+    f.fast_min_pad = std::numeric_limits<float>::infinity();
     f.sphere_ord.assign(spheres.size(), -1);
     f.tri_ord.assign(triangles.size(), -1);
     const size_t nRefs = f.prim_refs.size();
@@ -382,15 +383,23 @@ void Scene::buildFastStructure() {
         }
     }
 
-    // ---- padded primitive boxes.  The padding is orders of magnitude above the rounding error of
-    // the hit-distance arithmetic (which is worst for the radius-1000 ground sphere), so a
-    // primitive whose computed hit distance is accepted always lies inside its padded box.
+    // ---- padded primitive boxes.  The padding (2e-4 of the box's largest coordinate + 1e-4) is what
+    // keeps the fused box test conservative.  That test evaluates plane * inv - origin * inv with the
+    // second product rounded first, so in position terms its error is about
+    // (3 |origin| + 2 |plane|) * 2^-24: the |plane| part is covered 800 times over by the relative
+    // term, and the |origin| part is covered for ray origins up to fast_min_pad * 2^21 from the
+    // coordinate origin (a sixth of the smallest padding); rays that start further out never use this
+    // structure (fastTestUsable() in the kernels).  The hit-distance arithmetic of the primitives
+    // themselves (worst: the sphere discriminant near grazing incidence, whose error grows with the
+    // square of the distance to the sphere) is covered by margin, not by a bound.
     std::vector<PrimBox> prims;
     prims.reserve(spheres.size() + triangles.size());
-    auto pad = [](PrimBox& b) {
+    float minPad = std::numeric_limits<float>::infinity();
+    auto pad = [&minPad](PrimBox& b) {
         float m = 0.0f;
         for (int k = 0; k < 3; k++) m = std::max(m, std::max(std::fabs(b.mn[k]), std::fabs(b.mx[k])));
         const float d = 2e-4f * m + 1e-4f;
+        minPad = std::min(minPad, d);
         for (int k = 0; k < 3; k++) {
             b.mn[k] -= d;
             b.mx[k] += d;
@@ -419,6 +428,7 @@ void Scene::buildFastStructure() {
         pad(b);
         prims.push_back(b);
     }
+    f.fast_min_pad = minPad;
     if (prims.empty()) {
         // nothing to search: one entry with an inverted box and no leaf run (whatever its test
         // says, the walk ends without a hit)

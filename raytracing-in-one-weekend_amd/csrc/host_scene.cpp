@@ -514,7 +514,7 @@ int Scene::addMesh(const float* model16, int n_vertices, const float* positions,
         float uv[6] = {0.0f, 0.0f, 0.1f, 0.0f, 0.5f, 1.0f};  // Mesh.cpp:122-124 defaults
         for (int k = 0; k < 3; k++) {
             uint32_t vi = indices[3 * f + k];
-            if ((int)vi >= n_vertices) return -1;
+            if (vi >= (uint32_t)n_vertices) return -1;
             mulPoint(model16, &positions[3 * vi], 1.0f, &pos[3 * k]);  // Mesh.cpp:145-147
             if (uvs) {
                 uv[2 * k] = uvs[2 * vi];
@@ -612,28 +612,49 @@ int Scene::addMeshGltf(const float* model16, const char* path, int mat, int max_
         if (acc < 0 || acc >= (int)accessors->arr.size()) return false;
         const JValue& a = accessors->arr[acc];
         const JValue *bv = a.get("bufferView"), *cnt = a.get("count"), *ct = a.get("componentType");
-        if (!bv || !cnt || !ct) return false;
-        const JValue& v = views->arr[(int)bv->num];
+        if (!bv || !cnt || !ct || bv->t != JValue::NUM || cnt->t != JValue::NUM || ct->t != JValue::NUM) return false;
+        if (!(bv->num >= 0) || bv->num >= (double)views->arr.size() || !(cnt->num >= 0) || cnt->num > 4e9) return false;
+        const JValue& v = views->arr[(size_t)bv->num];
         const JValue *buf = v.get("buffer"), *off = v.get("byteOffset"), *st = v.get("byteStride");
-        size_t offset = (off ? (size_t)off->num : 0) + (a.get("byteOffset") ? (size_t)a.get("byteOffset")->num : 0);
-        const std::string& blob = blobs[buf ? (int)buf->num : 0];
+        const double bufIdx = buf ? buf->num : 0.0;
+        if (!(bufIdx >= 0) || bufIdx >= (double)blobs.size()) return false;
+        const double o1 = off ? off->num : 0.0, o2 = a.get("byteOffset") ? a.get("byteOffset")->num : 0.0;
+        const double strideNum = st ? st->num : (double)(ncomp * compSize);
+        if (!(o1 >= 0) || !(o2 >= 0) || o1 > 4e9 || o2 > 4e9 || !(strideNum >= (double)(ncomp * compSize)) || strideNum > 4e9)
+            return false;
+        const size_t offset = (size_t)o1 + (size_t)o2;
+        const std::string& blob = blobs[(size_t)bufIdx];
         out->count = (size_t)cnt->num;
         out->comp = (int)ct->num;
-        out->stride = st ? (size_t)st->num : ncomp * compSize;
+        out->stride = (size_t)strideNum;
         if (offset + (out->count ? (out->count - 1) * out->stride + ncomp * compSize : 0) > blob.size()) return false;
         out->data = blob.data() + offset;
         return true;
     };
+    // a JSON number used as an array index: -1 unless it is a number in int range
+    auto asIndex = [](const JValue* v) -> int {
+        return v && v->t == JValue::NUM && v->num >= 0 && v->num < 2147483647.0 ? (int)v->num : -1;
+    };
     View vp{}, vn{}, vt{}, vi{};
-    if (!view((int)attrs->get("POSITION")->num, 3, 4, &vp) || vp.comp != 5126) {
+    if (!view(asIndex(attrs->get("POSITION")), 3, 4, &vp) || vp.comp != 5126) {
         *err = "bad POSITION accessor";
         return -1;
     }
-    bool hasN = attrs->get("NORMAL") && view((int)attrs->get("NORMAL")->num, 3, 4, &vn) && vn.comp == 5126;
-    bool hasT = attrs->get("TEXCOORD_0") && view((int)attrs->get("TEXCOORD_0")->num, 2, 4, &vt) && vt.comp == 5126;
-    int idxComp = (int)accessors->arr[(int)idxAcc->num].get("componentType")->num;
+    // optional attributes: absent is fine, present but unreadable is an error
+    const bool hasN = attrs->get("NORMAL") != nullptr, hasT = attrs->get("TEXCOORD_0") != nullptr;
+    if ((hasN && !(view(asIndex(attrs->get("NORMAL")), 3, 4, &vn) && vn.comp == 5126)) ||
+        (hasT && !(view(asIndex(attrs->get("TEXCOORD_0")), 2, 4, &vt) && vt.comp == 5126))) {
+        *err = "bad NORMAL / TEXCOORD_0 accessor";
+        return -1;
+    }
+    int idxComp = 0;
+    const int idxAccI = asIndex(idxAcc);
+    if (idxAccI >= 0 && idxAccI < (int)accessors->arr.size()) {
+        const JValue* ct = accessors->arr[(size_t)idxAccI].get("componentType");
+        if (ct && ct->t == JValue::NUM) idxComp = (int)ct->num;
+    }
     size_t idxSize = idxComp == 5123 ? 2 : (idxComp == 5125 ? 4 : 0);
-    if (!idxSize || !view((int)idxAcc->num, 1, idxSize, &vi)) {
+    if (!idxSize || !view(idxAccI, 1, idxSize, &vi)) {
         *err = "bad index accessor";
         return -1;
     }

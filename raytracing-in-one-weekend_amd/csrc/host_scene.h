@@ -74,6 +74,11 @@ struct FlatScene {
     // The leaf runs are shared (fast_refs).  Empty for scenes that fit LDS.
     std::vector<uint32_t> fast_oct;
     int fast_oct_stride = 0;
+    // Smallest padding any primitive box of the search structure received.  The fused box test's
+    // rounding error grows with the ray origin's coordinates (it rounds origin * (1/d) before the
+    // subtraction), so rays that start further than fast_min_pad * 2^21 from the coordinate origin
+    // are not vouched for by the padding and walk the reference-order array instead.
+    float fast_min_pad = 0.0f;
     std::vector<int32_t> sphere_ord;    // sphere id   -> position in prim_refs (reference visit order)
     std::vector<int32_t> tri_ord;       // triangle id -> position in prim_refs
     std::vector<int32_t> prim_guard;    // position in prim_refs -> innermost box-tested entry of `nodes` above it, or -1

@@ -23,6 +23,7 @@ hipError_t launchTrace(const DevScene& sc, int n, const float* rays, int* kind, 
 hipError_t launchScatter(const DevScene& sc, int n, const int* mat, const float* rayIn, const float* p, const float* nrm,
                          const int* front, const float* uv, const unsigned int* key4, float* atten, float* rayOut,
                          int* alive, unsigned int* counterOut, hipStream_t stream);
+hipError_t launchReflectance(int n, const float* cosine, const float* refIdx, float* out, hipStream_t stream);
 hipError_t launchResolve(const float4* payloads, size_t stride4, int width, int height, int tiles_per_row_local,
                          int world, int only_rank, int mode, int spp, float4* out32, uint32_t* out8, hipStream_t stream);
 }  // namespace rt
@@ -552,6 +553,7 @@ int rt_upload_scene(rt_context* ctx, rt_scene* s) {
     d.n_fast_nodes = (int)(fastSrc.size() / 8);
     d.n_fast_refs = (int)sc.flat.fast_refs.size();
     d.force_ref = (ctx->force_ref || hugeCoords) ? 1 : 0;
+    d.origin_limit = sc.flat.fast_min_pad * 2097152.0f;  // 2^21, see buildFastStructure()
     ctx->huge_coords = hugeCoords;
     d.n_spheres = (int)sc.spheres.size();
     d.n_tris = (int)sc.triangles.size();
@@ -810,6 +812,23 @@ int rt_scatter_test(rt_context* ctx, int n, const int32_t* material, const float
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     (void)hipFree(d);
     if (e != hipSuccess) return fail(RT_ERR_HIP, std::string("scatter test: ") + hipGetErrorString(e));
+    return RT_OK;
+}
+
+int rt_reflectance_test(rt_context* ctx, int n, const float* cosine, const float* ref_idx, float* out) {
+    if (!ctx) return fail(RT_ERR_INVALID, "null context");
+    if (n <= 0 || !cosine || !ref_idx || !out) return fail(RT_ERR_INVALID, "bad arguments");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t N = (size_t)n;
+    float* d = nullptr;
+    HIP_TRY(hipMalloc((void**)&d, 12 * N));
+    hipError_t e = hipMemcpyAsync(d, cosine, 4 * N, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + N, ref_idx, 4 * N, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = rt::launchReflectance(n, d, d + N, d + 2 * N, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d + 2 * N, 4 * N, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(RT_ERR_HIP, std::string("reflectance test: ") + hipGetErrorString(e));
     return RT_OK;
 }
 

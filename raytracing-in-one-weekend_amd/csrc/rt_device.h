@@ -31,6 +31,7 @@ struct DevScene {
     int n_nodes, n_prim_refs, n_fast_nodes, n_fast_refs, n_spheres, n_tris, n_mats;
     int fast_oct_stride;      // > 0: fast_nodes holds 8 direction-ordered copies of this many entries each
     int force_ref;            // 1: always walk `nodes` in the reference's order (diagnostics)
+    float origin_limit;       // rays starting further than this from the coordinate origin (any axis) walk `nodes`
     float cam[22];            // origin, lowerLeftCorner, horizontal, vertical, u, v, w, lensRadius
     float bg[3];
 };

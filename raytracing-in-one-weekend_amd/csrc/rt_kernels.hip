@@ -329,13 +329,16 @@ __device__ __forceinline__ bool guardsPass(const SceneView& sv, const Ray& r, fl
     return true;
 }
 
-// True if the reciprocal direction is usable by the search structure's fused box test: every
-// component finite and small enough that plane * (1/d) cannot overflow (scene coordinates are
-// limited to 1e7 on upload).  False (also for NaN) sends the ray to the reference-order walk.
-__device__ __forceinline__ bool fastTestUsable(float invx, float invy, float invz, float nox, float noy, float noz) {
+// True if the search structure's fused box test may be used for this ray: every component of the
+// reciprocal direction finite and small enough that plane * (1/d) cannot overflow (scene coordinates
+// are limited to 1e7 on upload), and the origin within the distance from the coordinate origin up to
+// which the boxes' padding covers the test's rounding error (which grows with |origin|).  False (also
+// for NaN) sends the ray to the reference-order walk.
+__device__ __forceinline__ bool fastTestUsable(const V3& o, float originLimit, float invx, float invy, float invz, float nox,
+                                               float noy, float noz) {
     const float lim = 1e30f, inf = __builtin_inff();
     return fabsf(invx) < lim && fabsf(invy) < lim && fabsf(invz) < lim && fabsf(nox) < inf && fabsf(noy) < inf &&
-           fabsf(noz) < inf;
+           fabsf(noz) < inf && fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z)) <= originLimit;
 }
 
 // mWorld.Hit(r, 0.001f, infinity, rec) (R/src/Core/Raytracer.cpp:10): search structure first,
@@ -344,7 +347,8 @@ template <bool COUNT>
 __device__ __forceinline__ Hit closestHit(const DevScene& sc, const SceneView& sv, const Ray& r, Stats* st) {
     const float invx = 1.0f / r.d.x, invy = 1.0f / r.d.y, invz = 1.0f / r.d.z;
     const float a = dot(r.d, r.d);
-    if (!sc.force_ref && fastTestUsable(invx, invy, invz, -(r.o.x * invx), -(r.o.y * invy), -(r.o.z * invz))) {
+    if (!sc.force_ref &&
+        fastTestUsable(r.o, sc.origin_limit, invx, invy, invz, -(r.o.x * invx), -(r.o.y * invy), -(r.o.z * invz))) {
         bool bad = false;
         Hit h = traverseFast<COUNT>(sv, sc.n_fast_nodes, r, invx, invy, invz, a, bad, st);
         if (!bad && (h.ref == kNoHit || guardsPass<COUNT>(sv, r, invx, invy, invz, h, st))) return h;
@@ -426,6 +430,23 @@ __device__ __forceinline__ bool nearZero(V3 v) {
     return fabsf(v.x) <= lim && fabsf(v.y) <= lim && fabsf(v.z) <= lim;
 }
 
+// Dielectric::reflectance, R/src/Material/Material.h:90-95: r0 + (1 - r0) * pow(1 - cosine, 5), where
+// pow(float, int) and the sum run in double and the result is returned as float.  The C library's
+// pow is correctly rounded but for rare near-ties, so the fifth power is formed here to the same
+// standard: x^2 is exact in double (x has 24 significant bits), and the rounding residuals of the
+// two remaining products are recovered with fused multiply-adds and added back before the final
+// rounding.
+__device__ __forceinline__ float reflectance(float cosine, float refIdx) {
+    float r0 = (1 - refIdx) / (1 + refIdx);
+    r0 = r0 * r0;
+    const double x = (double)(1 - cosine);
+    const double x2 = x * x;                            // exact
+    const double x4 = x2 * x2, e4 = __builtin_fma(x2, x2, -x4);  // x^4 = x4 + e4
+    const double p = x4 * x, e5 = __builtin_fma(x4, x, -p);      // x4 * x = p + e5
+    const double x5 = p + (e5 + e4 * x);
+    return (float)((double)r0 + (double)(1 - r0) * x5);
+}
+
 // Material::scatter for the five material kinds (R/src/Material/Material.h:22-160).
 // Returns true if the path continues with `out` and `atten`; false ends it with `emit`.
 template <bool COUNT>
@@ -466,16 +487,7 @@ __device__ __forceinline__ bool scatter(const DevScene& sc, const SceneView& sv,
         float cosTheta = fminf(dot(-unit, s.n), 1.0f);
         float sinTheta = sqrtf(1.0f - cosTheta * cosTheta);
         bool reflectIt = ratio * sinTheta > 1.0f;
-        if (!reflectIt) {
-            // Schlick: r0 + (1 - r0) * pow(1 - cos, 5), evaluated in double as in the reference
-            float r0 = (1 - ratio) / (1 + ratio);
-            r0 = r0 * r0;
-            double x = (double)(1 - cosTheta);
-            double x2 = x * x;
-            double x5 = x2 * x2 * x;
-            float refl = (float)((double)r0 + (double)(1 - r0) * x5);
-            reflectIt = refl > rng.next();
-        }
+        if (!reflectIt) reflectIt = reflectance(cosTheta, ratio) > rng.next();
         if (reflectIt) {
             out.d = reflect(unit, s.n);
         } else {  // refract, R/src/Core/RTWeekend.cpp:45-51
@@ -723,6 +735,7 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
     }
     const int lane = threadIdx.x & 63;
     const int nNodesRef = sc.n_nodes, nNodesFast = sc.n_fast_nodes;
+    const float originLimit = sc.origin_limit;
     const int nTiles = a.n_local_tiles;
     const unsigned int nChunks = (unsigned int)nTiles * (unsigned int)a.n_samples;  // 64 units each
     const int boxKeep = a.knob[0];    // keep running BOX steps while at least this many lanes want one
@@ -776,7 +789,7 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
         nox = -(r.o.x * invx);
         noy = -(r.o.y * invy);
         noz = -(r.o.z * invz);
-        mode = (sc.force_ref || !fastTestUsable(invx, invy, invz, nox, noy, noz)) ? 1 : 0;
+        mode = (sc.force_ref || !fastTestUsable(r.o, originLimit, invx, invy, invz, nox, noy, noz)) ? 1 : 0;
         op = mode ? OP_REFBOX : OP_BOX;
         if (mode) idx = 0;  // the reference-order array has one order only
         if (COUNT) st.v[C_RAYS]++;
@@ -1151,6 +1164,12 @@ __global__ void scatterKernel(DevScene sc, int n, const int* mat, const float* r
     counterOut[i] = rng.counter;
 }
 
+// Dielectric::reflectance for n (cosine, refraction ratio) pairs (test hook).
+__global__ void reflectanceKernel(int n, const float* cosine, const float* refIdx, float* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = reflectance(cosine[i], refIdx[i]);
+}
+
 // Tiled rank payloads -> row-major image.  `payloads` holds `world` accumulation buffers of
 // `stride4` float4 each (world == 1 with rank r: only that rank's pixels are filled).
 // mode 0: RGBA32F sums with alpha 1; mode 1: writeColor bytes (R/src/Core/Raytracer.cpp:22-44).
@@ -1237,6 +1256,11 @@ hipError_t launchScatter(const DevScene& sc, int n, const int* mat, const float*
                          int* alive, unsigned int* counterOut, hipStream_t stream) {
     scatterKernel<<<(n + 63) / 64, 64, 0, stream>>>(sc, n, mat, rayIn, p, nrm, front, uv, key4, atten, rayOut, alive,
                                                    counterOut);
+    return hipGetLastError();
+}
+
+hipError_t launchReflectance(int n, const float* cosine, const float* refIdx, float* out, hipStream_t stream) {
+    reflectanceKernel<<<(n + 255) / 256, 256, 0, stream>>>(n, cosine, refIdx, out);
     return hipGetLastError();
 }
 

@@ -54,6 +54,35 @@ def cornell_mesh_scene(scene, width, height, mesh, textures, true_aspect=False, 
     return scene
 
 
+def instanced_mesh_scene(scene, mesh, copies, textures, spacing=0.09, scale=500.0):
+    """The large-mesh configuration: `copies` instances of one mesh on a jittered square grid over the
+    Cornell box's floor, every instance baked into ONE triangle list (the reference has no instancing:
+    Mesh::processMesh pre-transforms every vertex, R/src/Core/Mesh.cpp:106-208) and added as one Mesh
+    with an unlimited-depth BVH (the reference's depth-10 cap would leave list leaves of thousands of
+    triangles).  The grid jitter comes from the scene's own generator, so it is part of the scene's
+    random stream like everything else the reference draws.  Returns the triangle count."""
+    scene.cornell_box()
+    td = scene.add_texture(textures["diffuse"])
+    tr = scene.add_texture(textures["roughness"]) if textures.get("roughness") is not None else -1
+    mat = scene.add_pbr(td, tr, -1)
+    jit = scene.rng_floats(2 * copies)
+    side = int(np.ceil(np.sqrt(copies)))
+    nv = mesh["positions"].shape[0]
+    c = np.arange(copies)
+    off = np.zeros((copies, 3), np.float32)
+    off[:, 0] = ((c % side).astype(np.float32) + np.float32(0.3) * jit[0::2]) * np.float32(spacing) - np.float32(0.5 * spacing * side)
+    off[:, 2] = ((c // side).astype(np.float32) + np.float32(0.3) * jit[1::2]) * np.float32(spacing)
+    pos = (mesh["positions"][None, :, :] + off[:, None, :]).reshape(-1, 3)
+    idx = (mesh["indices"][None, :, :] + (c * nv).astype(np.uint32)[:, None, None]).reshape(-1, 3)
+    nrm = np.tile(mesh["normals"], (copies, 1)) if mesh.get("normals") is not None else None
+    uv = np.tile(mesh["uvs"], (copies, 1)) if mesh.get("uvs") is not None else None
+    scene.add_mesh(translate_scale((277.5, 100.0, 277.5), (scale, scale, scale)), pos, idx, mat, normals=nrm, uvs=uv,
+                   max_depth=-1)
+    scene.set_camera((278.0, 400.0, -800.0), (278.0, 150.0, 300.0), (0.0, 1.0, 0.0), 40.0, 1.0, 0.0, 10.0)
+    scene.set_background((0.6, 0.7, 0.9))
+    return idx.shape[0]
+
+
 def lathe_mesh(n_around=24, n_up=20, seed=0):
     """A vase-like surface of revolution in the brass vase's model units (height about 0.17,
     radius up to about 0.05), with smooth normals and texture coordinates: synthetic stand-in

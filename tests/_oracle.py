@@ -55,6 +55,7 @@ def lib():
                                   C.POINTER(C.c_uint32)]
         L.orc_texture_at.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.orc_texture_lut.argtypes = [C.c_void_p]
+        L.orc_reflectance.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_write_color.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         L.orc_render.argtypes = [C.c_void_p] + [C.c_int] * 10 + [C.c_void_p, C.c_void_p, C.POINTER(OrcCounters)]
         _lib = L
@@ -196,6 +197,13 @@ class OracleScene:
 
 def hash_random(x, y, sample, counter):
     return lib().orc_hash_random(x, y, sample, counter)
+
+
+def reflectance(cosine, ref_idx):
+    cosine, ref_idx = _f32(cosine), _f32(ref_idx)
+    out = np.zeros(cosine.size, np.float32)
+    lib().orc_reflectance(cosine.size, _p(cosine), _p(ref_idx), _p(out))
+    return out
 
 
 def texture_lut():
