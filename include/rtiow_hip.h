@@ -199,6 +199,17 @@ int rt_clear(rt_context* ctx);
  * launches) and is added per pixel in sample order, so the sums have the bits of the reference's
  * sequential `pixelColor +=`.  Asynchronous on the context's stream unless the buffer must grow. */
 int rt_render(rt_context* ctx, int first_sample, int n_samples, int max_depth);
+/* rt_render() for callers that cannot allocate device memory: code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc.  No counterpart in the reference.  Same work,
+ * same bits as rt_render(), but the per-sample colour buffer and the queue counter live in a fixed
+ * array inside the library (64 MiB + 256 bytes per GPU in use, held until the process ends), so the
+ * call allocates and frees nothing; a sample range that needs more colour space than that runs as
+ * several launches.  Fails with RT_ERR_LIMIT when the context's share of the frame has more than
+ * rt_noalloc_max_pixels() pixel slots (4,194,304: one sample of every slot must fit).  Every call on
+ * one GPU uses that GPU's array: calls that overlap in time on one GPU (other contexts, other
+ * streams) race and must be serialised by the caller. */
+int rt_render_noalloc(rt_context* ctx, int first_sample, int n_samples, int max_depth);
+size_t rt_noalloc_max_pixels(void);
 /* Blocks until the stream is idle (the join in runRaytracer(), RaytracingApplication.cpp:269). */
 int rt_sync(rt_context* ctx);
 /* Raytracer::Cancel() (Raytracer.h:59-62,77-80): makes a running rt_run() stop at the next

@@ -15,7 +15,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("RTIOW_LIB", os.path.join(_HERE, "librtiow_hip.so"))  # RTIOW_LIB: experimental builds
+LIB_PATH = os.environ.get("RTIOW_LIB") or os.path.join(_HERE, "librtiow_hip.so")  # RTIOW_LIB: experimental builds
 if not os.path.exists(LIB_PATH):
     raise ImportError(
         f"{LIB_PATH} is missing: build it with `make -C {_HERE}/csrc` "
@@ -83,6 +83,8 @@ SYMBOLS = {
     "rt_accum_bytes": (C.c_size_t, [_I, _I, _I]),
     "rt_clear": (_I, [_VP]),
     "rt_render": (_I, [_VP, _I, _I, _I]),
+    "rt_render_noalloc": (_I, [_VP, _I, _I, _I]),
+    "rt_noalloc_max_pixels": (C.c_size_t, []),
     "rt_sync": (_I, [_VP]),
     "rt_cancel": (_I, [_VP]),
     "rt_run": (_I, [_VP, _I, _I, _I, PASS_CALLBACK, _VP]),
@@ -312,6 +314,9 @@ class Context:
 
     def render(self, first_sample, n_samples, max_depth=50):
         _check(lib.rt_render(self.h, first_sample, n_samples, max_depth))
+
+    def render_noalloc(self, first_sample, n_samples, max_depth=50):
+        _check(lib.rt_render_noalloc(self.h, first_sample, n_samples, max_depth))
 
     def sync(self):
         _check(lib.rt_sync(self.h))

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -59,7 +60,19 @@ struct rt_context {
     size_t colors_cap = 0;     // in float4
 };
 
+// Scratch of rt_render_noalloc(): the queue counter (first 256 bytes) and the per-sample colour
+// buffer of one launch.  One copy per GPU the library runs on, held until the process ends.  The
+// name is a host-side stand-in, never a device address: host code uses the per-device pointer
+// that rt_create() obtains with hipGetSymbolAddress().
+constexpr size_t kScratchQueueBytes = 256;
+constexpr size_t kScratchColorBytes = size_t(RT_NOALLOC_SCRATCH_MB) << 20;
+static __device__ __align__(256) unsigned char scratch[kScratchQueueBytes + kScratchColorBytes];
+
 namespace {
+
+constexpr int kMaxDevices = 64;
+std::mutex g_scratchMutex;
+unsigned char* g_scratchPtr[kMaxDevices] = {nullptr};  // per device: address of its copy of `scratch`
 
 thread_local std::string g_err;
 int fail(int code, const std::string& msg) {
@@ -144,19 +157,26 @@ int checkRenderState(rt_context* ctx) {
 // Launch shape.  Default: the persistent wavefront loop, three 512-thread workgroups per CU
 // whose waves pull chunks of 64 pixel samples from a queue.  RT_KERNEL=simple selects the plain
 // one-wave-per-tile kernel (kept for A/B measurements); both produce identical images.
-int launch(rt_context* ctx, rt::RenderArgs& a, bool count) {
+// Where a render call keeps the per-sample colours and the queue counter of its launches.
+struct Workspace {
+    float4* colors;        // null: the context's own buffer, grown on demand
+    size_t colors_cap;     // in float4
+    unsigned int* queue;
+};
+
+int launch(rt_context* ctx, rt::RenderArgs& a, bool count, const Workspace* fixed = nullptr) {
     const int threads = 256;
     const int wavesPerBlock = threads / 64;
     const char* kernel = std::getenv("RT_KERNEL");
     const bool simple = kernel && std::strcmp(kernel, "simple") == 0;
     int blocks;
-    if (simple) {
+    if (simple && !fixed) {
         blocks = (a.n_local_tiles + wavesPerBlock - 1) / wavesPerBlock;
         if (blocks < 1) blocks = 1;
         HIP_TRY(rt::launchRender(a, ctx->use_lds, count, blocks, threads, ctx->stream));
         return RT_OK;
     }
-    a.queue = ctx->queue;
+    a.queue = fixed ? fixed->queue : ctx->queue;
     a.knob[0] = envInt("RT_BOX_KEEP", 8);
     a.knob[1] = envInt("RT_SHADE_MIN", 32);
     a.knob[3] = std::max(1, envInt("RT_PRIM_KEEP", 16));
@@ -172,7 +192,14 @@ int launch(rt_context* ctx, rt::RenderArgs& a, bool count) {
     // adds them per pixel in sample order; launches are cut so that the buffer stays within
     // RT_COLORS_MB (default 4096) and the queue index within 32 bits.
     const long long nSlots = (long long)a.n_local_tiles * 64;
-    const size_t budget = (size_t)std::max(16, envInt("RT_COLORS_MB", 4096)) << 20;
+    size_t budget = (size_t)std::max(16, envInt("RT_COLORS_MB", 4096)) << 20;
+    if (fixed) {
+        if ((size_t)nSlots > fixed->colors_cap)
+            return fail(RT_ERR_LIMIT, "rt_render_noalloc: this context's share of the frame (" + std::to_string(nSlots) +
+                                          " pixel slots) exceeds the fixed scratch of " +
+                                          std::to_string(fixed->colors_cap) + " slots");
+        budget = std::min(budget, fixed->colors_cap * sizeof(float4));
+    }
     size_t maxSamples = std::max<size_t>(1, budget / ((size_t)nSlots * 16));
     maxSamples = std::min<size_t>(maxSamples, (size_t)((1ll << 31) / nSlots));
     maxSamples = std::max<size_t>(1, std::min<size_t>(maxSamples, (size_t)a.n_samples));
@@ -180,7 +207,7 @@ int launch(rt_context* ctx, rt::RenderArgs& a, bool count) {
     for (int s0 = 0; s0 < total; s0 += (int)maxSamples) {
         const int ns = std::min((int)maxSamples, total - s0);
         const size_t need = (size_t)nSlots * (size_t)ns;
-        if (need > ctx->colors_cap) {
+        if (!fixed && need > ctx->colors_cap) {
             HIP_TRY(hipStreamSynchronize(ctx->stream));
             if (ctx->colors) (void)hipFree(ctx->colors);
             ctx->colors = nullptr;
@@ -190,12 +217,12 @@ int launch(rt_context* ctx, rt::RenderArgs& a, bool count) {
         }
         a.first_sample = first + s0;
         a.n_samples = ns;
-        a.colors = ctx->colors;
+        a.colors = fixed ? fixed->colors : ctx->colors;
         int blocks = maxBlocks;
         const long long needed = ((long long)a.n_local_tiles * ns + wfWaves - 1) / wfWaves;
         if (blocks > needed) blocks = (int)needed;
         if (blocks < 1) blocks = 1;
-        HIP_TRY(hipMemsetAsync(ctx->queue, 0, 256, ctx->stream));
+        HIP_TRY(hipMemsetAsync(a.queue, 0, 256, ctx->stream));
         HIP_TRY(rt::launchWavefront(a, ctx->use_lds, count, blocks, wfThreads, ctx->stream));
     }
     return RT_OK;
@@ -398,6 +425,16 @@ int rt_create(int device, rt_context** out) {
         return fail(RT_ERR_NO_DEVICE, "no HIP device available; this library has no CPU path");
     if (device < 0 || device >= n) return fail(RT_ERR_INVALID, "device index out of range");
     HIP_TRY(hipSetDevice(device));
+    if (device >= kMaxDevices) return fail(RT_ERR_LIMIT, "device index beyond the library's table");
+    {
+        // this device's copy of the scratch array: looked up once per device, with that device current
+        std::lock_guard<std::mutex> lock(g_scratchMutex);
+        if (!g_scratchPtr[device]) {
+            unsigned char* p = nullptr;
+            HIP_TRY(hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch)));
+            g_scratchPtr[device] = p;
+        }
+    }
     rt_context* ctx = new rt_context();
     ctx->device = device;
     hipDeviceProp_t prop;
@@ -635,6 +672,29 @@ int rt_render(rt_context* ctx, int first_sample, int n_samples, int max_depth) {
     rt::RenderArgs a = makeArgs(ctx, first_sample, n_samples, max_depth);
     HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
     rc = launch(ctx, a, false);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+    ctx->timed = true;
+    return RT_OK;
+}
+
+size_t rt_noalloc_max_pixels(void) { return kScratchColorBytes / sizeof(float4); }
+
+int rt_render_noalloc(rt_context* ctx, int first_sample, int n_samples, int max_depth) {
+    int rc = checkRenderState(ctx);
+    if (rc) return rc;
+    if (first_sample < 0 || n_samples < 0) return fail(RT_ERR_INVALID, "negative sample range");
+    if ((long long)first_sample + n_samples > (1 << 24))
+        return fail(RT_ERR_LIMIT, "sample index beyond 2^24 (the RNG key is the sample index as a float)");
+    if (n_samples == 0) return RT_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    unsigned char* base = g_scratchPtr[ctx->device];
+    if (!base) return fail(RT_ERR_STATE, "the scratch array of this device was never looked up");
+    Workspace ws{reinterpret_cast<float4*>(base + kScratchQueueBytes), kScratchColorBytes / sizeof(float4),
+                 reinterpret_cast<unsigned int*>(base)};
+    rt::RenderArgs a = makeArgs(ctx, first_sample, n_samples, max_depth);
+    HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+    rc = launch(ctx, a, false, &ws);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
     ctx->timed = true;

@@ -55,6 +55,11 @@ struct RenderArgs {
     float4* colors;
 };
 
+// Megabytes of the fixed colour scratch behind rt_render_noalloc() (one copy per GPU in use).
+#ifndef RT_NOALLOC_SCRATCH_MB
+#define RT_NOALLOC_SCRATCH_MB 64
+#endif
+
 constexpr int kTile = 8;  // one wave64 = one 8x8 pixel tile
 
 // largest workgroup the persistent kernel is compiled for (its launch bounds)
