@@ -37,4 +37,4 @@ waves = vals[13]
 total = sum(ticks)
 print(f"{which}: {waves} waves, {total / max(waves, 1):.0f} ticks per wave")
 for n, t in zip(names, ticks):
-    print(f"  {n:32s} {100.0 * t / max(total, 1):5.1f} %")
+    print(f"  {n:32s} {100.0 * t / max(total, 1):5.1f} %   {t / max(waves, 1):12.0f} ticks per wave")

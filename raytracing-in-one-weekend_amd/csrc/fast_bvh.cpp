@@ -383,22 +383,39 @@ void Scene::buildFastStructure() {
         }
     }
 
-    // ---- padded primitive boxes.  The padding (2e-4 of the box's largest coordinate + 1e-4) is what
-    // keeps the fused box test conservative.  That test evaluates plane * inv - origin * inv with the
-    // second product rounded first, so in position terms its error is about
-    // (3 |origin| + 2 |plane|) * 2^-24: the |plane| part is covered 800 times over by the relative
-    // term, and the |origin| part is covered for ray origins up to fast_min_pad * 2^21 from the
-    // coordinate origin (a sixth of the smallest padding); rays that start further out never use this
+    // ---- padded primitive boxes.  The padding is what keeps the fused box test conservative.  That
+    // test evaluates plane * inv - origin * inv with the second product rounded first, so in position
+    // terms its error is about (3 |origin| + 2 |plane|) * 2^-24.  The |plane| part is covered 800
+    // times over by the relative term 2e-4 * (the box's largest coordinate) + 1e-4.  The |origin| part
+    // is covered for ray origins up to pad * 2^21 from the coordinate origin (a sixth of the padding),
+    // so every box is padded by at least extent * 2^-21, where `extent` is the largest coordinate of
+    // any primitive: rays start at the camera or on a primitive, and paths do reach the far side of
+    // the largest one (a path that gets inside the cover scene's ground sphere bounces around in it,
+    // 2000 units from the small spheres, until the depth limit).  For primitives tiny against the
+    // scene that floor is capped at a tenth of their own size; rays that start further than
+    // fast_min_pad * 2^21 from the coordinate origin (a far camera, or the capped case) never use this
     // structure (fastTestUsable() in the kernels).  The hit-distance arithmetic of the primitives
     // themselves (worst: the sphere discriminant near grazing incidence, whose error grows with the
     // square of the distance to the sphere) is covered by margin, not by a bound.
     std::vector<PrimBox> prims;
     prims.reserve(spheres.size() + triangles.size());
+    float extent = 0.0f;
+    for (size_t i = 0; i < spheres.size(); i++)
+        if (f.sphere_ord[i] >= 0)
+            for (int k = 0; k < 3; k++) extent = std::max(extent, std::fabs(spheres[i].c[k]) + std::fabs(spheres[i].r));
+    for (size_t i = 0; i < triangles.size(); i++)
+        if (f.tri_ord[i] >= 0)
+            for (int k = 0; k < 9; k++) extent = std::max(extent, std::fabs(triangles[i].pos[k]));
+    const float originFloor = extent * (1.01f / 2097152.0f);
     float minPad = std::numeric_limits<float>::infinity();
-    auto pad = [&minPad](PrimBox& b) {
-        float m = 0.0f;
-        for (int k = 0; k < 3; k++) m = std::max(m, std::max(std::fabs(b.mn[k]), std::fabs(b.mx[k])));
-        const float d = 2e-4f * m + 1e-4f;
+    auto pad = [&minPad, originFloor](PrimBox& b) {
+        float m = 0.0f, size = 0.0f;
+        for (int k = 0; k < 3; k++) {
+            m = std::max(m, std::max(std::fabs(b.mn[k]), std::fabs(b.mx[k])));
+            size = std::max(size, b.mx[k] - b.mn[k]);
+        }
+        const float own = 2e-4f * m + 1e-4f;
+        const float d = std::max(own, std::min(originFloor, 0.1f * size));
         minPad = std::min(minPad, d);
         for (int k = 0; k < 3; k++) {
             b.mn[k] -= d;
