@@ -4,19 +4,24 @@ max depth 50, one frame of 64 samples per pixel per GPU per step.
     python bench.py --gpus N --steps K --warmup W
     (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
-One step = clear the accumulation buffer + one render launch of `spp` samples of every owned
-pixel (+ for N > 1 one all-gather of the rank payloads over RCCL and the device resolve into the
-row-major RGBA32F frame).  N GPUs shard the 8x8-pixel tiles of the same 1080p frame and each
-renders 64*N samples per pixel of its tiles, so per-GPU work is fixed ("weak" scaling) and the
-gathered frame is a 64*N-spp image.  The scene lives in device memory before timing starts; the
-frame stays in device memory (copying it to the host as RGBA8 adds 8.3 MB over PCIe, about 0.2 ms).
+One step = clear the accumulation buffer, one render call of `spp` samples of every owned pixel,
+(N > 1: one all-gather of the rank payloads over RCCL), the device resolve into the row-major
+RGBA8 frame the reference hands to glTexImage2D, and the copy of that frame (8.3 MB) to pinned
+host memory on rank 0.  The scene lives in device memory before timing starts.
+
+N GPUs shard the 8x8-pixel tiles of the same 1080p frame.  The headline value keeps per-GPU work
+fixed ("weak" scaling): each rank renders 64*N samples per pixel of its tiles, so the gathered
+frame is a 64*N-spp image.  A second timed loop splits ONE 64-spp frame over the N ranks (strong
+scaling: the latency of the frame BASELINE.json's metric names) and is reported beside it.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -43,26 +48,34 @@ def flops_from_counters(c):
 
 
 SHADER_CLOCK_HZ = 2.4e9  # MI355X peak engine clock, the one the 157.3 TFLOP/s figure is quoted at
+KERNEL_SOURCES = ("rt_kernels.hip", "rt_device.h")
 
 
-def profiled(world, spp, key):
-    """A figure of the committed PMC passes (profiles/hbm_traffic.json) for the profiled configuration."""
+def kernel_source_hash():
+    """SHA-256 over the kernel sources the committed PMC figures were measured on."""
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "raytracing-in-one-weekend_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def profiled(world, spp):
+    """The committed PMC figures (profiles/hbm_traffic.json, written by profiles/summarize_traffic.py
+    from rocprofv3 passes over this same workload) -- or {} when they do not describe this run: another
+    configuration, or kernel sources that changed since the passes were made (the file records the
+    hash of the sources it was measured on)."""
     path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if world != 1 or spp != SPP or not os.path.exists(path):
-        return None
+        return {}
     with open(path) as f:
-        return json.load(f).get(key)
-
-
-def hbm_traffic_bytes(world, spp):
-    """HBM bytes per render launch from the committed rocprofv3 PMC passes (profiles/hbm_traffic.json,
-    written by profiles/summarize_traffic.py from the FETCH_SIZE / WRITE_SIZE runs of this same
-    workload); None when the run's configuration is not the profiled one."""
-    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if world != 1 or spp != SPP or not os.path.exists(path):
-        return None
-    with open(path) as f:
-        return json.load(f).get("hbm_bytes_per_launch")
+        d = json.load(f)
+    try:
+        if d.get("kernel_source_sha256") != kernel_source_hash():
+            return {}
+    except OSError:
+        return {}
+    return d
 
 
 def main():
@@ -113,24 +126,28 @@ def main():
     n4 = tiling.payload_float4s(W, H, world)
     payload = torch.zeros(n4, 4, dtype=torch.float32, device=dev)
     gathered = torch.zeros(world * n4, 4, dtype=torch.float32, device=dev) if world > 1 else None  # rank payloads end to end
-    frame = torch.zeros(H, W, 4, dtype=torch.float32, device=dev) if world > 1 else None
+    frame8 = torch.zeros(H, W, 4, dtype=torch.uint8, device=dev) if world > 1 else None
+    host8 = torch.zeros(H, W, 4, dtype=torch.uint8).pin_memory()   # what the application would upload as a texture
     ctx.set_target(W, H, rank, world, external_ptr=payload.data_ptr())
-    spp_step = args.spp * world  # per-GPU work fixed: 1/world of the tiles, world x the samples
     kernel_ms = []
 
-    def step(record):
+    def step(spp_step, record=False):
         payload.zero_()
         ctx.render(0, spp_step, MAX_DEPTH)
         if record:
             kernel_ms.append(ctx.last_render_ms())
-        if world > 1:
-            if args.backend == "nccl":
-                dist.all_gather_into_tensor(gathered, payload)
-            else:
-                host = torch.empty(gathered.shape, dtype=gathered.dtype)
-                dist.all_gather_into_tensor(host, payload.cpu())
-                gathered.copy_(host)
-            ctx.resolve_gathered(gathered.data_ptr(), world, frame.data_ptr())
+        if world == 1:
+            ctx.read_rgba8_into(spp_step, host8.data_ptr())   # resolve + copy to the host; blocks
+            return
+        if args.backend == "nccl":
+            dist.all_gather_into_tensor(gathered, payload)
+        else:
+            host = torch.empty(gathered.shape, dtype=gathered.dtype)
+            dist.all_gather_into_tensor(host, payload.cpu())
+            gathered.copy_(host)
+        ctx.resolve_gathered_rgba8(gathered.data_ptr(), world, spp_step, frame8.data_ptr())
+        if rank == 0:
+            host8.copy_(frame8, non_blocking=True)
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -143,26 +160,33 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    for _ in range(args.warmup):
-        step(False)
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(False)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        elapsed = max_over_ranks(elapsed)
+    def timed(spp_step, steps, warmup):
+        for _ in range(warmup):
+            step(spp_step)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(spp_step)
+        fence()
+        dt = time.perf_counter() - t0
+        return max_over_ranks(dt) if world > 1 else dt
+
+    spp_weak = args.spp * world  # per-GPU work fixed: 1/world of the tiles, world x the samples
+    elapsed = timed(spp_weak, args.steps, args.warmup)
+    # Strong scaling: ONE args.spp-sample frame split over the ranks (for one rank the same workload).
+    elapsed_strong = timed(args.spp, args.steps, 1) if world > 1 else elapsed
 
     # Kernel duration by HIP events on the launch stream, in separate untimed steps (reading an
     # event blocks the host, which must not sit inside the timed region).
     for _ in range(3):
-        step(True)
+        step(spp_weak, True)
     fence()
     avg_kernel_ms = float(np.mean(kernel_ms))
 
-    samples_per_step = W * H * args.spp * world  # whole job: every pixel, spp*world samples
+    samples_per_step = W * H * spp_weak  # whole job: every pixel, spp * world samples
     value = samples_per_step * args.steps / elapsed / 1e6
+    ms_step = 1e3 * elapsed / args.steps
+    ms_strong = 1e3 * elapsed_strong / args.steps
 
     out = {
         "metric": "Msamples/s (1080p, 50 bounces)",
@@ -171,7 +195,7 @@ def main():
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+        "ms_per_step": round(ms_step, 4),
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -179,44 +203,56 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": f"Book-1 cover scene (488 spheres, BVH(world)), {W}x{H}, {args.spp} spp per GPU per step "
-                        f"({spp_step} spp frame), max depth 50, progressive accumulation",
+                        f"({spp_weak} spp frame), max depth 50, progressive accumulation; a step ends with the "
+                        f"RGBA8 frame in host memory",
             "samples_per_step": samples_per_step,
             "parallelism": f"tiles8x8 sharded over {world} rank(s)" + ((", all-gather (RCCL)" if args.backend == "nccl" else ", all-gather (gloo rehearsal through host memory)") if world > 1 else ""),
-            "ms_per_64spp_frame": round(1e3 * elapsed / args.steps * 64.0 / spp_step, 4),
+            "render_kernels_ms": round(avg_kernel_ms, 4),
+            "resolve_gather_copy_ms": round(ms_step - avg_kernel_ms, 4),
+            "strong_scaling": {
+                "what": f"one {args.spp}-spp {W}x{H} frame split over {world} rank(s): render + gather + resolve + copy to host",
+                "ms_per_64spp_frame": round(ms_strong * 64.0 / args.spp, 4),
+                "msamples_per_s": round(W * H * args.spp / (ms_strong * 1e-3) / 1e6, 2),
+            },
         },
     }
 
     if args.check and world > 1:
         fence()
+        step(spp_weak)
+        fence()
         if rank == 0:
             solo = rt.Context(local_rank)
             solo.upload_scene(scene)
             solo.set_target(W, H)
-            solo.render(0, spp_step, MAX_DEPTH)
+            solo.render(0, spp_weak, MAX_DEPTH)
             solo.sync()
             want = solo.read_accum()
+            want8 = solo.read_rgba8(spp_weak)
             solo.close()
-            got = frame.cpu().numpy()
+            got = tiling.image_from_payloads(gathered.cpu().numpy().reshape(world, n4, 4), W, H, world)
             same = bool(np.array_equal(got[..., :3].view(np.uint32), want[..., :3].view(np.uint32)))
-            out["gathered_frame_equals_single_rank_render"] = same
-            if not same:
+            same8 = bool(np.array_equal(host8.numpy(), want8))
+            out["gathered_frame_equals_single_rank_render"] = same and same8
+            if not (same and same8):
                 raise SystemExit("gathered frame differs from the single-rank render")
         fence()
 
     if rank == 0:
         # Algorithmic flops per launch from the kernel's own path statistics (a counting launch
         # over the same pixels and samples, untimed), priced with COST.
-        counters = ctx.count(0, min(spp_step, 8), MAX_DEPTH)
+        counters = ctx.count(0, min(spp_weak, 8), MAX_DEPTH)
         flops_per_sample = flops_from_counters(counters) / counters["samples"]
-        own_samples = W * H * spp_step / world
+        own_samples = W * H * spp_weak / world
         achieved = flops_per_sample * own_samples / (avg_kernel_ms * 1e-3) / 1e12
+        prof = profiled(world, args.spp)
         out["roofline"] = {
             "bound": "valu_fp32",
             "achieved": round(achieved, 3),
             "peak": PEAK_FP32_TFLOPS,
             "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_FP32_TFLOPS, 4),
-            "traffic": hbm_traffic_bytes(world, args.spp),
+            "traffic": prof.get("hbm_bytes_per_launch"),   # null when the PMC passes predate the kernel sources
             "kernel": "rt::renderWavefront<true, false, false>",
             "kernel_ms": round(avg_kernel_ms, 4),
             "flops_per_sample": round(flops_per_sample, 1),
@@ -226,12 +262,12 @@ def main():
         }
         # What does bound the loop: vector-instruction issue.  Wave-instructions per launch from the
         # committed PMC pass, 2 cycles each on a SIMD, over the SIMD-cycles of the launch measured here.
-        valu = profiled(world, args.spp, "valu_insts_per_launch")
+        valu = prof.get("valu_insts_per_launch")
         if valu:
             prop = torch.cuda.get_device_properties(dev)
             simd_cycles = prop.multi_processor_count * 4 * avg_kernel_ms * 1e-3 * SHADER_CLOCK_HZ
             out["roofline"]["valu_issue_frac"] = round(2.0 * valu / simd_cycles, 3)
-            out["roofline"]["lane_utilisation"] = round(profiled(world, args.spp, "lane_utilisation") or 0.0, 3)
+            out["roofline"]["lane_utilisation"] = round(prof.get("lane_utilisation") or 0.0, 3)
     ctx.close()
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -256,6 +292,22 @@ def main():
         t0 = time.perf_counter()
         flat.render(sw, sh, 0, 1, MAX_DEPTH, rng_mode=1, order=1, threads=1)
         dt_flat1 = time.perf_counter() - t0
+        # The reference's own CPU-runnable case: 1200x675 at 10 spp, written as image.ppm, on all the
+        # threads and on two fewer (RaytracerMT starts hardware_concurrency() - 2 workers,
+        # R/src/Core/Raytracer.cpp:136).
+        cw, ch, cspp = 1200, 675, 10
+        c1 = orc.OracleScene()
+        scenes.cover_scene(c1, cw, ch, wrap_bvh=True)
+        t0 = time.perf_counter()
+        _, c1_rgba8, _ = c1.render(cw, ch, 0, cspp, MAX_DEPTH, rng_mode=1, order=1, threads=threads)
+        dt_c1 = time.perf_counter() - t0
+        ppm = os.path.join(tempfile.gettempdir(), "image.ppm")
+        rt.write_ppm(ppm, c1_rgba8)
+        ppm_bytes = os.path.getsize(ppm)
+        t2 = max(1, threads - 2)
+        t0 = time.perf_counter()
+        c1.render(cw, ch, 0, cspp, MAX_DEPTH, rng_mode=1, order=1, threads=t2)
+        dt_c1_t2 = time.perf_counter() - t0
         out["cpu_baseline"] = {
             "value": round(W * H * cpu_spp / dt / 1e6, 3),
             "unit": "Msamples/s",
@@ -266,6 +318,10 @@ def main():
             "one_thread_bvh": round(sw * sh * sspp / dt_bvh1 / 1e6, 4),
             "one_thread_flat_list": round(sw * sh / dt_flat1 / 1e6, 4),
             "one_thread_sample": f"{sw}x{sh}, {sspp} spp (BVH) and 1 spp (flat list, as the reference application renders)",
+            "c1_1200x675x10": {"msamples_per_s": round(cw * ch * cspp / dt_c1 / 1e6, 3), "threads": threads,
+                               "seconds": round(dt_c1, 3), "image_ppm_bytes": ppm_bytes},
+            "c1_threads_minus_2": {"msamples_per_s": round(cw * ch * cspp / dt_c1_t2 / 1e6, 3), "threads": t2,
+                                   "seconds": round(dt_c1_t2, 3)},
         }
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -240,6 +240,11 @@ int rt_write_ppm(const char* path, int width, int height, const uint8_t* rgba8);
  * of every rank's accumulation buffer) into a row-major RGBA32F device image. */
 int rt_resolve_gathered(rt_context* ctx, const void* device_payloads, int world, void* device_rgba32f);
 
+/* The same resolve straight to writeColor()'s bytes (Raytracer.cpp:22-44): a row-major W*H RGBA8
+ * device image, row 0 = bottom, ready for one device-to-host copy into the buffer glTexImage2D uploads. */
+int rt_resolve_gathered_rgba8(rt_context* ctx, const void* device_payloads, int world, int samples_per_pixel,
+                              void* device_rgba8);
+
 /* Test hook: closest hit of n rays (origin xyz, direction xyz) with tMin = 0.001, as
  * mWorld.Hit(r, 0.001f, infinity, rec) (Raytracer.cpp:10).  prim_kind: -1 miss, 0 sphere,
  * 1 triangle.  Optional outputs may be NULL.  Host pointers; blocking. */

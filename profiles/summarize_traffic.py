@@ -12,6 +12,10 @@ import sqlite3
 import sys
 
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import kernel_source_hash  # noqa: E402
+
+
 def per_dispatch(root, counter):
     """Average per dispatch of the render kernel plus average per dispatch of the ordered-sum kernel
     that follows every render launch."""
@@ -55,7 +59,9 @@ def main(root):
            "hbm_bytes_per_launch": None if rd is None or wr is None else int((2.0 * rd + wr) * 1024),
            "valu_insts_per_launch": valu,
            "lane_utilisation": None if not (active and lanes) else lanes / (64.0 * active),
-           "workload": "bench.py default: cover scene 1920x1080, 64 spp, 1 GPU"}
+           "workload": "bench.py default: cover scene 1920x1080, 64 spp, 1 GPU",
+           # bench.py reports these figures only while the kernel sources still hash to this
+           "kernel_source_sha256": kernel_source_hash()}
     here = os.path.dirname(os.path.abspath(__file__))
     with open(os.path.join(here, "hbm_traffic.json"), "w") as f:
         json.dump(out, f, indent=1)

@@ -92,6 +92,7 @@ SYMBOLS = {
     "rt_read_rgba8": (_I, [_VP, _I, _VP]),
     "rt_write_ppm": (_I, [C.c_char_p, _I, _I, _VP]),
     "rt_resolve_gathered": (_I, [_VP, _VP, _I, _VP]),
+    "rt_resolve_gathered_rgba8": (_I, [_VP, _VP, _I, _I, _VP]),
     "rt_trace": (_I, [_VP, _I] + [_VP] * 7),
     "rt_scatter_test": (_I, [_VP, _I] + [_VP] * 11),
     "rt_reflectance_test": (_I, [_VP, _I, _VP, _VP, _VP]),
@@ -338,8 +339,16 @@ class Context:
         _check(lib.rt_read_rgba8(self.h, samples_per_pixel, _p(out)))
         return out
 
+    def read_rgba8_into(self, samples_per_pixel, host_ptr):
+        """rt_read_rgba8 into caller memory of W*H*4 bytes (e.g. a pinned staging buffer)."""
+        _check(lib.rt_read_rgba8(self.h, samples_per_pixel, C.c_void_p(host_ptr)))
+
     def resolve_gathered(self, payload_ptr, world, out_ptr):
         _check(lib.rt_resolve_gathered(self.h, C.c_void_p(payload_ptr), world, C.c_void_p(out_ptr)))
+
+    def resolve_gathered_rgba8(self, payload_ptr, world, samples_per_pixel, out_ptr):
+        _check(lib.rt_resolve_gathered_rgba8(self.h, C.c_void_p(payload_ptr), world, samples_per_pixel,
+                                             C.c_void_p(out_ptr)))
 
     def trace(self, rays):
         rays = _f32(rays).reshape(-1, 6)

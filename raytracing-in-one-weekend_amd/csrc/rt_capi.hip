@@ -58,6 +58,8 @@ struct rt_context {
     unsigned long long sched_stats[14] = {0};  // from the last rt_count(): {executions, lanes} per operation
     float4* colors = nullptr;  // per-sample radiance of the split mode (grown on demand)
     size_t colors_cap = 0;     // in float4
+    void* resolved = nullptr;  // row-major image the read-out calls resolve into (grown on demand, kept)
+    size_t resolved_cap = 0;   // in bytes
 };
 
 // Scratch of rt_render_noalloc(): the queue counter (first 256 bytes) and the per-sample colour
@@ -460,6 +462,7 @@ void rt_destroy(rt_context* ctx) {
     freeScene(ctx);
     freeTarget(ctx);
     if (ctx->colors) (void)hipFree(ctx->colors);
+    if (ctx->resolved) (void)hipFree(ctx->resolved);
     if (ctx->queue) (void)hipFree(ctx->queue);
     if (ctx->counters) (void)hipFree(ctx->counters);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -736,20 +739,27 @@ int rt_run(rt_context* ctx, int samples_per_pixel, int samples_per_pass, int max
     return RT_OK;
 }
 
+// Resolves the tiled accumulation buffer into the context's row-major staging image (kept between
+// calls: a progressive display reads once per pass) and copies it to `dst`.
 static int readResolved(rt_context* ctx, int mode, int spp, void* dst, size_t bytes) {
     int rc = checkRenderState(ctx);
     if (rc) return rc;
     if (!dst) return fail(RT_ERR_INVALID, "null destination");
     HIP_TRY(hipSetDevice(ctx->device));
-    void* d = nullptr;
-    HIP_TRY(hipMalloc(&d, bytes));
+    if (bytes > ctx->resolved_cap) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (ctx->resolved) (void)hipFree(ctx->resolved);
+        ctx->resolved = nullptr;
+        ctx->resolved_cap = 0;
+        HIP_TRY(hipMalloc(&ctx->resolved, bytes));
+        ctx->resolved_cap = bytes;
+    }
+    void* d = ctx->resolved;
     const int only = ctx->world > 1 ? ctx->rank : -1;
-    hipError_t e = rt::launchResolve(ctx->accum, 0, ctx->width, ctx->height, ctx->tprl, ctx->world, only, mode, spp,
-                                     reinterpret_cast<float4*>(d), reinterpret_cast<uint32_t*>(d), ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(dst, d, bytes, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    (void)hipFree(d);
-    if (e != hipSuccess) return fail(RT_ERR_HIP, std::string("resolve: ") + hipGetErrorString(e));
+    HIP_TRY(rt::launchResolve(ctx->accum, 0, ctx->width, ctx->height, ctx->tprl, ctx->world, only, mode, spp,
+                              reinterpret_cast<float4*>(d), reinterpret_cast<uint32_t*>(d), ctx->stream));
+    HIP_TRY(hipMemcpyAsync(dst, d, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
     return RT_OK;
 }
 int rt_read_accum_rgba32f(rt_context* ctx, float* dst) {
@@ -793,6 +803,19 @@ int rt_resolve_gathered(rt_context* ctx, const void* device_payloads, int world,
     HIP_TRY(rt::launchResolve(reinterpret_cast<const float4*>(device_payloads), stride4, ctx->width, ctx->height,
                               ctx->tprl, world, -1, 0, 1, reinterpret_cast<float4*>(device_rgba32f), nullptr,
                               ctx->stream));
+    return RT_OK;
+}
+
+int rt_resolve_gathered_rgba8(rt_context* ctx, const void* device_payloads, int world, int samples_per_pixel,
+                              void* device_rgba8) {
+    if (!ctx || !device_payloads || !device_rgba8) return fail(RT_ERR_INVALID, "null argument");
+    if (world != ctx->world) return fail(RT_ERR_INVALID, "world differs from rt_set_target()");
+    if (samples_per_pixel < 1) return fail(RT_ERR_INVALID, "samples_per_pixel must be positive");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t stride4 = rt_accum_bytes(ctx->width, ctx->height, world) / sizeof(float4);
+    HIP_TRY(rt::launchResolve(reinterpret_cast<const float4*>(device_payloads), stride4, ctx->width, ctx->height,
+                              ctx->tprl, world, -1, 1, samples_per_pixel, nullptr,
+                              reinterpret_cast<uint32_t*>(device_rgba8), ctx->stream));
     return RT_OK;
 }
 

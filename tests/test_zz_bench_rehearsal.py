@@ -32,3 +32,51 @@ def test_two_rank_bench_step_gathers_the_single_rank_frame():
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["gathered_frame_equals_single_rank_render"] is True
     assert out["config"]["samples_per_step"] == 1920 * 1080 * 2 * 2
+
+
+RCCL_ONE_RANK = r"""
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, os.getcwd())
+from __graft_entry__ import load_package
+rt = load_package()
+from rtiow_amd import scenes, tiling
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+w, h, spp = 320, 180, 2
+scene = rt.Scene()
+scenes.cover_scene(scene, w, h)
+ctx = rt.Context(0)
+stream = torch.cuda.Stream(dev)
+torch.cuda.set_stream(stream)
+ctx.set_stream(stream.cuda_stream)
+ctx.upload_scene(scene)
+n4 = tiling.payload_float4s(w, h, 1)
+payload = torch.zeros(n4, 4, dtype=torch.float32, device=dev)
+gathered = torch.zeros(n4, 4, dtype=torch.float32, device=dev)
+frame = torch.zeros(h, w, 4, dtype=torch.float32, device=dev)
+frame8 = torch.zeros(h, w, 4, dtype=torch.uint8, device=dev)
+ctx.set_target(w, h, 0, 1, external_ptr=payload.data_ptr())
+ctx.render(0, spp, 50)
+dist.all_gather_into_tensor(gathered, payload)          # RCCL, on the render stream
+ctx.resolve_gathered(gathered.data_ptr(), 1, frame.data_ptr())
+ctx.resolve_gathered_rgba8(gathered.data_ptr(), 1, spp, frame8.data_ptr())
+torch.cuda.synchronize(dev)
+want, want8 = ctx.read_accum(), ctx.read_rgba8(spp)
+assert np.array_equal(frame.cpu().numpy().view(np.uint32), want.view(np.uint32))
+assert np.array_equal(frame8.cpu().numpy(), want8)
+assert want[..., :3].max() > 0
+dist.destroy_process_group()
+print("rccl-one-rank-ok")
+"""
+
+
+def test_rccl_all_gather_feeds_the_device_resolve():
+    """The collective leg of the bench step with the real backend (RCCL), as far as one GPU allows:
+    a one-rank process group, all_gather_into_tensor on the render stream, both device resolves."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()))
+    res = subprocess.run([sys.executable, "-c", RCCL_ONE_RANK], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and "rccl-one-rank-ok" in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]
