@@ -212,13 +212,21 @@ int rt_render_noalloc(rt_context* ctx, int first_sample, int n_samples, int max_
 size_t rt_noalloc_max_pixels(void);
 /* Blocks until the stream is idle (the join in runRaytracer(), RaytracingApplication.cpp:269). */
 int rt_sync(rt_context* ctx);
-/* Raytracer::Cancel() (Raytracer.h:59-62,77-80): makes a running rt_run() stop at the next
- * pass boundary.  Thread-safe. */
+/* Raytracer::Cancel() (Raytracer.h:59-62,77-80; the reference polls its flag once per scanline,
+ * Raytracer.cpp:54,78,148,176).  Makes a running rt_run() stop: the flag lives in pinned host memory that
+ * the running kernel's waves read every time they fetch 64 samples of work, so a pass stops within the
+ * time its longest paths in flight take, not at the next pass boundary.  A Cancel() that arrives before
+ * rt_run() starts stops that run; the flag is cleared when rt_run() returns and by rt_set_target().
+ * Thread-safe; the one call that may be made while another call on the context is running. */
 int rt_cancel(rt_context* ctx);
 
 /* Complete progressive render: passes of `samples_per_pass` until `samples_per_pixel` are
  * done or rt_cancel() is called; after each pass `on_pass(done, user)` may be invoked
- * (NULL = no callback).  Stands in for Raytracer::Run() (Raytracer.cpp:46-95,134-194). */
+ * (NULL = no callback).  Stands in for Raytracer::Run() (Raytracer.cpp:46-95,134-194).
+ * Cancelled: returns RT_ERR_CANCELLED.  A kernel launch that the flag cut short adds nothing to the
+ * accumulation buffer, so every pixel always holds the same number of samples; if that is more than
+ * the last callback reported (a pass that ran as several launches), the callback is invoked once more
+ * with that number before rt_run() returns. */
 typedef void (*rt_pass_callback)(int samples_done, void* user);
 int rt_run(rt_context* ctx, int samples_per_pixel, int samples_per_pass, int max_depth, rt_pass_callback on_pass,
            void* user);

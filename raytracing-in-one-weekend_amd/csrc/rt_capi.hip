@@ -53,6 +53,9 @@ struct rt_context {
     unsigned int* queue = nullptr;
     unsigned long long* counters = nullptr;
     std::atomic<int> cancel{0};
+    int* cancel_host = nullptr;   // pinned, device-visible copy of the flag the running kernels poll
+    int* cancel_dev = nullptr;
+    bool cancellable = false;     // set by rt_run() around its render calls
     int force_ref = 0;
     bool huge_coords = false;
     unsigned long long sched_stats[14] = {0};  // from the last rt_count(): {executions, lanes} per operation
@@ -121,6 +124,11 @@ void freeTarget(rt_context* ctx) {
     ctx->accum_owned = false;
 }
 
+void clearCancel(rt_context* ctx) {
+    ctx->cancel.store(0);
+    if (ctx->cancel_host) __atomic_store_n(ctx->cancel_host, 0, __ATOMIC_RELEASE);
+}
+
 void tileGeometry(int width, int height, int world, int* tiles_x, int* tiles_y, int* tprl) {
     *tiles_x = (width + rt::kTile - 1) / rt::kTile;
     *tiles_y = (height + rt::kTile - 1) / rt::kTile;
@@ -132,6 +140,7 @@ rt::RenderArgs makeArgs(rt_context* ctx, int first_sample, int n_samples, int ma
     a.sc = ctx->dsc;
     a.accum = ctx->accum;
     a.queue = nullptr;
+    a.cancel = ctx->cancellable ? ctx->cancel_dev : nullptr;
     a.counters = ctx->counters;
     a.width = ctx->width;
     a.height = ctx->height;
@@ -447,6 +456,11 @@ int rt_create(int device, rt_context** out) {
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
     if (e == hipSuccess) e = hipMalloc((void**)&ctx->queue, 256);
     if (e == hipSuccess) e = hipMalloc((void**)&ctx->counters, 256);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&ctx->cancel_host, sizeof(int), hipHostMallocMapped);
+    if (e == hipSuccess) {
+        *ctx->cancel_host = 0;
+        e = hipHostGetDevicePointer((void**)&ctx->cancel_dev, ctx->cancel_host, 0);
+    }
     if (e != hipSuccess) {
         rt_destroy(ctx);
         return fail(RT_ERR_HIP, std::string("context set-up: ") + hipGetErrorString(e));
@@ -465,6 +479,7 @@ void rt_destroy(rt_context* ctx) {
     if (ctx->resolved) (void)hipFree(ctx->resolved);
     if (ctx->queue) (void)hipFree(ctx->queue);
     if (ctx->counters) (void)hipFree(ctx->counters);
+    if (ctx->cancel_host) (void)hipHostFree(ctx->cancel_host);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -633,6 +648,7 @@ static int setTarget(rt_context* ctx, int width, int height, int rank, int world
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     freeTarget(ctx);
+    clearCancel(ctx);
     ctx->width = width;
     ctx->height = height;
     ctx->rank = rank;
@@ -714,6 +730,16 @@ int rt_sync(rt_context* ctx) {
 int rt_cancel(rt_context* ctx) {
     if (!ctx) return fail(RT_ERR_INVALID, "null context");
     ctx->cancel.store(1);
+    if (ctx->cancel_host) __atomic_store_n(ctx->cancel_host, 1, __ATOMIC_RELEASE);  // what the running kernels see
+    return RT_OK;
+}
+
+// Samples every owned pixel holds: the .w of the first accumulation slot (launches are all-or-nothing).
+static int samplesAccumulated(rt_context* ctx, int* out) {
+    float4 first;
+    HIP_TRY(hipMemcpyAsync(&first, ctx->accum, sizeof first, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    *out = (int)first.w;
     return RT_OK;
 }
 
@@ -722,19 +748,31 @@ int rt_run(rt_context* ctx, int samples_per_pixel, int samples_per_pass, int max
     int rc = checkRenderState(ctx);
     if (rc) return rc;
     if (samples_per_pixel < 0 || samples_per_pass < 1) return fail(RT_ERR_INVALID, "bad sample counts");
-    ctx->cancel.store(0);
+    // The flag is not cleared here: a Cancel() that arrived just before Run() still stops it.  It is
+    // cleared when Run() returns.
     rc = rt_clear(ctx);
-    if (rc) return rc;
     int done = 0;
-    while (done < samples_per_pixel) {
-        if (ctx->cancel.load()) return fail(RT_ERR_CANCELLED, "render cancelled");
+    ctx->cancellable = true;
+    while (rc == RT_OK && done < samples_per_pixel) {
+        if (ctx->cancel.load()) break;
         int n = std::min(samples_per_pass, samples_per_pixel - done);
         rc = rt_render(ctx, done, n, max_depth);
-        if (rc) return rc;
-        rc = rt_sync(ctx);
-        if (rc) return rc;
+        if (rc == RT_OK) rc = rt_sync(ctx);
+        if (rc != RT_OK || ctx->cancel.load()) break;   // a pass the flag may have cut short is settled below
         done += n;
         if (on_pass) on_pass(done, user);
+    }
+    ctx->cancellable = false;
+    const bool cancelled = ctx->cancel.load() != 0;
+    clearCancel(ctx);
+    if (rc != RT_OK) return rc;
+    if (cancelled) {
+        // Launches are all-or-nothing (a launch the flag cut short adds nothing), so every pixel holds the
+        // same number of samples; when that is more than the last callback reported, report it.
+        int have = done;
+        if (ctx->n_local_tiles > 0 && (rc = samplesAccumulated(ctx, &have)) != RT_OK) return rc;
+        if (have > done && on_pass) on_pass(have, user);
+        return fail(RT_ERR_CANCELLED, "render cancelled");
     }
     return RT_OK;
 }

@@ -39,7 +39,8 @@ struct DevScene {
 struct RenderArgs {
     DevScene sc;
     float4* accum;        // tiled: [local tile][lane] -> {r, g, b, samples}
-    unsigned int* queue;  // next-slot counter of the persistent launch shape (may be null)
+    unsigned int* queue;  // [0] next-chunk counter of the persistent launch shape, [1] set when the launch was cut short (may be null)
+    const int* cancel;    // host-pinned flag the persistent waves read when they fetch a chunk (null: not cancellable)
     unsigned long long* counters;  // path statistics (counting launches only)
     int width, height;
     int tiles_x, tiles_y;      // 8x8-pixel tiles

@@ -763,7 +763,19 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
     int chunkSample = 0, chunkX0 = 0, chunkY0 = 0;
     bool chunkInside = false;
     unsigned int chunkAhead = 0;  // lane 0: the queue index fetched ahead of need
-    if (lane == 0) chunkAhead = atomicAdd(a.queue, 1u);
+    // Raytracer::Cancel() (R/src/Core/Raytracer.h:59-62; the reference polls its flag once per scanline,
+    // Raytracer.cpp:54,78,148,176): every fetch of a chunk index also reads the caller's flag from pinned
+    // host memory.  Once it is up the wave takes no more chunks (the paths it holds run to their end) and
+    // marks the launch as cut short, which makes accumulateColors() leave the image alone.
+    auto fetchChunk = [&]() {
+        unsigned int c = atomicAdd(a.queue, 1u);
+        if (a.cancel && __hip_atomic_load(a.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) {
+            a.queue[1] = 1u;
+            c = 0xFFFFFFFFu;
+        }
+        return c;
+    };
+    if (lane == 0) chunkAhead = fetchChunk();
     unsigned long long schedExec[7] = {0, 0, 0, 0, 0, 0, 0}, schedLanes[7] = {0, 0, 0, 0, 0, 0, 0};
     // TIME: ticks per stretch of the loop (T_* below); tMark = last reading
     enum { T_BOX, T_PRIM, T_GUARD, T_SURFACE, T_SCATTER, T_SHADE_TAIL, T_FINISH, T_REFILL, T_CAMERA, T_REFBOX, T_REST, T_N };
@@ -1002,7 +1014,7 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
                 } else {
                     // and fetch the one after it now: the atomic's round trip to L2 (thousands of
                     // cycles) is over long before this wave needs the index
-                    if (lane == 0) chunkAhead = atomicAdd(a.queue, 1u);
+                    if (lane == 0) chunkAhead = fetchChunk();
                     chunk = (int)c;
                     chunkNext = 0;
                     // chunk -> (sample, tile) -> the tile's corner pixel, all wave-uniform
@@ -1078,6 +1090,7 @@ __global__ void __launch_bounds__(256) accumulateColors(RenderArgs a) {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     const int nSlots = a.n_local_tiles * 64;
     if (q >= nSlots) return;
+    if (a.queue && a.queue[1]) return;  // the render launch was cancelled part-way: its samples are dropped
     const int tile = q >> 6, l = q & 63;
     const int ty = tile / a.tiles_per_row_local;
     const int k = tile - ty * a.tiles_per_row_local;

@@ -534,3 +534,64 @@ def test_device_error_paths(rt, scenes, gpu_ctx):
     c.sync()
     assert not c.read_accum()[..., :3].any()
     c.close()
+
+
+def test_cancel_stops_a_long_single_pass(rt, scenes, gpu_ctx):
+    """Raytracer::Cancel() from another thread while ONE pass of 2048 spp is running (no pass boundary
+    to wait for: the reference polls per scanline, R/src/Core/Raytracer.cpp:54,78).  rt_run returns
+    RT_ERR_CANCELLED long before the pass could have finished, every pixel holds the same whole number
+    of samples, and they are exactly the first samples of the sequence."""
+    import threading
+    import time
+    w, h, spp = 1280, 720, 2048
+    a = rt.Scene()
+    scenes.cover_scene(a, w, h)
+    gpu_ctx.upload_scene(a)
+    gpu_ctx.set_target(w, h)
+    gpu_ctx.render(0, 64, 50)           # time 64 spp to know what the whole pass would cost
+    gpu_ctx.sync()
+    full_estimate = gpu_ctx.last_render_ms() * (spp / 64) / 1e3
+    assert full_estimate > 0.25
+    seen, result = [], {}
+
+    def run():
+        t0 = time.perf_counter()
+        try:
+            gpu_ctx.run(spp, spp, 50, on_pass=seen.append)
+            result["code"] = 0
+        except rt.RtError as e:
+            result["code"] = e.code
+        result["t_end"] = time.perf_counter()
+        result["t0"] = t0
+
+    th = threading.Thread(target=run)
+    th.start()
+    time.sleep(0.06)
+    t_cancel = time.perf_counter()
+    gpu_ctx.cancel()
+    th.join(timeout=30)
+    assert not th.is_alive()
+    assert result["code"] == rt.RT_ERR_CANCELLED
+    latency = result["t_end"] - t_cancel
+    assert latency < 0.1, latency                      # the paths in flight finish; nothing new starts
+    assert result["t_end"] - result["t0"] < 0.6 * full_estimate
+    img = gpu_ctx.read_accum()
+    done = seen[-1] if seen else 0
+    assert 0 <= done < spp
+    assert (img[..., 3] == 1.0).all()
+    if done:
+        want = render_gpu(gpu_ctx, w, h, 0, done)
+        assert np.array_equal(bits(img), bits(want))
+    else:
+        assert not img[..., :3].any()
+    # the flag was cleared on return: the next run completes
+    gpu_ctx.set_target(64, 36)
+    gpu_ctx.run(2, 1, 50)
+    # and a Cancel() that arrives BEFORE Run() stops that run at once
+    gpu_ctx.cancel()
+    with pytest.raises(rt.RtError) as e:
+        gpu_ctx.run(4, 1, 50)
+    assert e.value.code == rt.RT_ERR_CANCELLED
+    gpu_ctx.sync()
+    assert not gpu_ctx.read_accum()[..., :3].any()
+    gpu_ctx.run(2, 1, 50)               # cleared again
