@@ -99,6 +99,23 @@ int rt_scene_add_mesh(rt_scene* s, const float* model16, int n_vertices, const f
  * Texture images are not decoded here; bind them through `material`. */
 int rt_scene_add_mesh_gltf(rt_scene* s, const float* model16, const char* gltf_path, int material, int max_depth);
 
+/* Ingestion of a Hittable tree the caller has ALREADY built -- e.g. a Scene whose world holds a
+ * BVHNode or a Mesh -- without re-building it (no random number is drawn, the caller's boxes are used
+ * as they are).  Everything added between a begin call and the matching rt_scene_end_group() becomes a
+ * child, in order, of that group instead of the world; groups nest.
+ *   rt_scene_begin_bvh_node(box): a BVHNode with its public `box` (R/src/AccelerationStructures/Bvh.h:
+ *     96-99): add `left`, then `right` (once, when both point at the same object: a span-1 node tests
+ *     its only child twice with the same outcome).  Its Hit() -- box test, left, then right against
+ *     the closer of tMax and left's hit (Bvh.h:80-88) -- is a box test followed by a closest-hit scan.
+ *   rt_scene_begin_mesh(box): a Mesh with its BoundingBox() (R/src/Core/Mesh.h:13-37): add the
+ *     members of its `triangles` vector in order (after construction that is the one BVH root).
+ *   rt_scene_begin_list(): a HittableList (R/src/Core/Hittable.h:272-316): add `objects` in order.
+ * box = {min.x, min.y, min.z, max.x, max.y, max.z}.  Returns a non-negative group id. */
+int rt_scene_begin_bvh_node(rt_scene* s, const float* box6);
+int rt_scene_begin_mesh(rt_scene* s, const float* box6);
+int rt_scene_begin_list(rt_scene* s);
+int rt_scene_end_group(rt_scene* s);
+
 /* world = randomScene()  (R/src/RaytracingApplication.cpp:359-405), drawn in g++ argument order. */
 int rt_scene_random_scene(rt_scene* s);
 /* world = cornellBox()   (R/src/RaytracingApplication.cpp:407-478). */

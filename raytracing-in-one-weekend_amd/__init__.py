@@ -62,6 +62,10 @@ SYMBOLS = {
     "rt_scene_add_box": (_I, [_VP, _VP, _VP, _I, _VP]),
     "rt_scene_add_mesh": (_I, [_VP, _VP, _I, _VP, _VP, _VP, _I, _VP, _I, _I]),
     "rt_scene_add_mesh_gltf": (_I, [_VP, _VP, C.c_char_p, _I, _I]),
+    "rt_scene_begin_bvh_node": (_I, [_VP, _VP]),
+    "rt_scene_begin_mesh": (_I, [_VP, _VP]),
+    "rt_scene_begin_list": (_I, [_VP]),
+    "rt_scene_end_group": (_I, [_VP]),
     "rt_scene_random_scene": (_I, [_VP]),
     "rt_scene_cornell_box": (_I, [_VP]),
     "rt_scene_wrap_bvh": (_I, [_VP]),
@@ -196,6 +200,20 @@ class Scene:
     def add_mesh_gltf(self, model, path, material, max_depth=10):
         m = _f32(model, 16)
         return _check(lib.rt_scene_add_mesh_gltf(self.h, _p(m), path.encode(), material, max_depth))
+
+    def begin_bvh_node(self, box6):
+        b = _f32(box6, 6)
+        return _check(lib.rt_scene_begin_bvh_node(self.h, _p(b)))
+
+    def begin_mesh(self, box6):
+        b = _f32(box6, 6)
+        return _check(lib.rt_scene_begin_mesh(self.h, _p(b)))
+
+    def begin_list(self):
+        return _check(lib.rt_scene_begin_list(self.h))
+
+    def end_group(self):
+        _check(lib.rt_scene_end_group(self.h))
 
     def random_scene(self):
         _check(lib.rt_scene_random_scene(self.h))

@@ -308,7 +308,7 @@ int Scene::addPbr(int td, int tr, int tn) {
 }
 int Scene::addSphere(float cx, float cy, float cz, float r, int mat) {
     spheres.push_back({{cx, cy, cz}, r, mat});
-    world.push_back({Obj::SPHERE, (int)spheres.size() - 1});
+    place({Obj::SPHERE, (int)spheres.size() - 1});
     flat.valid = false;
     return (int)spheres.size() - 1;
 }
@@ -324,7 +324,7 @@ int Scene::newTriangle(const float* pos9, const float* nrm9, const float* uv6, i
 }
 int Scene::addTriangle(const float* pos9, const float* nrm9, const float* uv6, int mat) {
     int id = newTriangle(pos9, nrm9, uv6, mat);
-    world.push_back({Obj::TRIANGLE, id});
+    place({Obj::TRIANGLE, id});
     return id;
 }
 
@@ -360,8 +360,37 @@ int Scene::addBox(const float* p0, const float* p1, int mat, const float* model1
         c.objs.push_back({Obj::TRIANGLE, id});
     }
     composites.push_back(std::move(c));
-    world.push_back({Obj::COMPOSITE, (int)composites.size() - 1});
+    place({Obj::COMPOSITE, (int)composites.size() - 1});
     return first;
+}
+
+void Scene::place(const Obj& o) {
+    if (open_groups_.empty())
+        world.push_back(o);
+    else
+        composites[open_groups_.back()].objs.push_back(o);
+    flat.valid = false;
+}
+
+int Scene::beginGroup(bool boxed, const float* box6) {
+    Composite c;
+    c.kind = boxed ? Composite::MESH : Composite::LIST;  // MESH: box test, then the children in order
+    c.has_box_test = boxed;
+    for (int k = 0; k < 3; k++) {
+        c.box.mn[k] = boxed ? box6[k] : 0.0f;
+        c.box.mx[k] = boxed ? box6[3 + k] : 0.0f;
+    }
+    composites.push_back(std::move(c));
+    const int id = (int)composites.size() - 1;
+    place({Obj::COMPOSITE, id});
+    open_groups_.push_back(id);
+    return id;
+}
+
+int Scene::endGroup() {
+    if (open_groups_.empty()) return -1;
+    open_groups_.pop_back();
+    return 0;
 }
 
 Box3 Scene::objectBox(const Obj& o) const {
@@ -552,8 +581,7 @@ int Scene::addMesh(const float* model16, int n_vertices, const float* positions,
     composites.push_back(std::move(bvh));
     mesh.objs.push_back({Obj::COMPOSITE, (int)composites.size() - 1});
     composites.push_back(std::move(mesh));
-    world.push_back({Obj::COMPOSITE, (int)composites.size() - 1});
-    flat.valid = false;
+    place({Obj::COMPOSITE, (int)composites.size() - 1});
     return first;
 }
 

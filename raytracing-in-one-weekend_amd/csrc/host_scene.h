@@ -116,6 +116,14 @@ public:
     int addMesh(const float* model16, int n_vertices, const float* positions, const float* normals, const float* uvs,
                 int n_triangles, const uint32_t* indices, int mat, int max_depth);
     int addMeshGltf(const float* model16, const char* path, int mat, int max_depth, std::string* err);
+    // Ingestion of a tree the caller has already built (no random numbers are drawn): objects added
+    // between beginGroup() and endGroup() become the children, in order, of one composite.
+    // boxed = true: the caller's box is tested first, then the children are scanned with the running
+    // closest hit -- BVHNode::Hit (left, then right; R/src/AccelerationStructures/Bvh.h:80-88) and
+    // Mesh::Hit (R/src/Core/Mesh.h:13-31) alike.  boxed = false: a plain HittableList.
+    int beginGroup(bool boxed, const float* box6);
+    int endGroup();
+    bool groupsOpen() const { return !open_groups_.empty(); }
     void randomScene();
     void cornellBox();
     void wrapBvh();
@@ -137,6 +145,8 @@ public:
     FlatScene flat;
 
 private:
+    std::vector<int> open_groups_;  // composites under construction, innermost last
+    void place(const Obj& o);       // appends to the innermost open group, or to the world
     int newTriangle(const float* pos9, const float* nrm9, const float* uv6, int mat);
     struct BoxedObj {
         Obj obj;

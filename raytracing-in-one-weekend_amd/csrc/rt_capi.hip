@@ -319,8 +319,23 @@ int rt_scene_cornell_box(rt_scene* s) {
     s->sc.cornellBox();
     return RT_OK;
 }
+int rt_scene_begin_bvh_node(rt_scene* s, const float* box6) {
+    if (!s || !box6) return fail(RT_ERR_INVALID, "bad arguments");
+    return s->sc.beginGroup(true, box6);
+}
+int rt_scene_begin_mesh(rt_scene* s, const float* box6) { return rt_scene_begin_bvh_node(s, box6); }
+int rt_scene_begin_list(rt_scene* s) {
+    if (!s) return fail(RT_ERR_INVALID, "null scene");
+    return s->sc.beginGroup(false, nullptr);
+}
+int rt_scene_end_group(rt_scene* s) {
+    if (!s) return fail(RT_ERR_INVALID, "null scene");
+    if (s->sc.endGroup() < 0) return fail(RT_ERR_STATE, "rt_scene_end_group() without an open group");
+    return RT_OK;
+}
 int rt_scene_wrap_bvh(rt_scene* s) {
     if (!s) return fail(RT_ERR_INVALID, "null scene");
+    if (s->sc.groupsOpen()) return fail(RT_ERR_STATE, "a group is still open");
     if (s->sc.world.empty()) return fail(RT_ERR_STATE, "cannot build a BVH over an empty world");
     s->sc.wrapBvh();
     return RT_OK;
@@ -346,6 +361,7 @@ int rt_scene_set_background(rt_scene* s, float r, float g, float b) {
 
 int rt_scene_flatten(rt_scene* s, rt_flat_info* info) {
     if (!s) return fail(RT_ERR_INVALID, "null scene");
+    if (s->sc.groupsOpen()) return fail(RT_ERR_STATE, "a group is still open (rt_scene_end_group() missing)");
     s->sc.flatten();
     if (info) {
         const rt::Scene& sc = s->sc;
@@ -505,6 +521,7 @@ int rt_upload_scene(rt_context* ctx, rt_scene* s) {
     if (!ctx || !s) return fail(RT_ERR_INVALID, "null handle");
     HIP_TRY(hipSetDevice(ctx->device));
     rt::Scene& sc = s->sc;
+    if (sc.groupsOpen()) return fail(RT_ERR_STATE, "a group is still open (rt_scene_end_group() missing)");
     sc.flatten();
     for (const auto& m : sc.materials)
         if (m.kind == RT_MAT_PBR && (m.tex_d < 0 || m.tex_d >= (int)sc.textures.size()))

@@ -595,3 +595,22 @@ def test_cancel_stops_a_long_single_pass(rt, scenes, gpu_ctx):
     gpu_ctx.sync()
     assert not gpu_ctx.read_accum()[..., :3].any()
     gpu_ctx.run(2, 1, 50)               # cleared again
+
+
+def test_ingested_tree_renders_like_the_built_one(rt, orc, scenes, gpu_ctx):
+    """A scene whose BVH was handed in node by node (rt_scene_begin_bvh_node ...) renders the same bits
+    as the scene whose BVH the library built, which in turn equals the oracle."""
+    from test_host_flatten import rebuild_through_group_calls
+    w, h, spp = 160, 90, 2
+    a, o = both(rt, orc, lambda s: scenes.cover_scene(s, w, h))
+    b = rt.Scene()
+    fa = a.get_flat()
+    for k in range(fa["info"].n_materials):
+        b.add_material(int(fa["mat_kind"][k]), fa["mat_rgbp"][k][:3], float(fa["mat_rgbp"][k][3]))
+    rebuild_through_group_calls(rt, a, b)
+    b.set_camera((13.0, 2.0, 3.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 20.0, scenes.aspect_ratio(w, h), 0.1, 10.0)
+    b.set_background(scenes.COVER_BACKGROUND)
+    gpu_ctx.upload_scene(b)
+    got = render_gpu(gpu_ctx, w, h, 0, spp)
+    want, _, _ = o.render(w, h, 0, spp, 50, rng_mode=1, order=1, threads=8)
+    assert np.array_equal(bits(got[..., :3]), bits(want[..., :3]))

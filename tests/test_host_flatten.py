@@ -237,3 +237,105 @@ def test_threaded_build_equals_the_serial_one_and_the_oracle(rt, orc, monkeypatc
     assert np.array_equal(after_a.view(np.uint32), c.rng_floats(4).view(np.uint32))   # same generator state
     check_structure(flat, *b.dump_tree())
     assert np.array_equal(after_a.view(np.uint32), b.rng_floats(4).view(np.uint32))
+
+
+def rebuild_through_group_calls(rt, src_scene, dst_scene):
+    """Walks the flattened tree of `src_scene` the way an adapter walks an existing Hittable tree
+    (BVHNode: box, left, right; list: objects in order) and hands it to `dst_scene` through the
+    ingestion calls.  Returns {kind: [source id of destination primitive k]}."""
+    f = src_scene.get_flat()
+    nodes, refs = f["nodes"], f["prim_refs"]
+    order = {0: [], 1: []}
+
+    def add_prim(ref):
+        kind, pid = (ref >> 30) & 1, int(ref & 0x3FFFFFFF)
+        order[kind].append(pid)
+        if kind == 0:
+            c = f["spheres"][pid]
+            dst_scene.add_sphere(c[:3], float(c[3]), int(f["sphere_mat"][pid]))
+        else:
+            dst_scene.add_triangle(f["tri_pos"][pid], int(f["tri_mat"][pid]), f["tri_normal"][pid], f["tri_uv"][pid])
+
+    def emit(i):
+        w = nodes[i]
+        skip, nobox, first = int(w[3] & 0x3FFFFFFF), bool(w[3] & (1 << 30)), int(np.int32(w[7]))
+        if nobox:
+            dst_scene.begin_list()
+        else:
+            dst_scene.begin_bvh_node(np.concatenate([w[0:3], w[4:7]]).view(np.float32))
+        if first >= 0:
+            p = first
+            while True:
+                add_prim(int(refs[p]))
+                if refs[p] >> 31:
+                    break
+                p += 1
+        j = i + 1
+        while j < skip:
+            j = emit(j)
+        dst_scene.end_group()
+        return skip
+
+    j = 0
+    while j < len(nodes):
+        j = emit(j)
+    return order
+
+
+@pytest.mark.parametrize("which", ["cover", "cornell_vase", "mixed"])
+def test_caller_built_tree_is_ingested_as_it_is(rt, scenes, which):
+    """rt_scene_begin_bvh_node / begin_list / end_group: a tree handed in node by node flattens to the
+    same entries (boxes, skip links, leaf runs) as the tree the library built itself, without a single
+    random number being drawn."""
+    a = rt.Scene()
+    if which == "cover":
+        scenes.cover_scene(a, 320, 180)
+    elif which == "cornell_vase":
+        mesh = scenes.load_gltf_mesh(os.path.join(G, "brass_vase", "brass_vase_04_4k.gltf"))
+        tex = {"diffuse": scenes.noise_texture(16, 1), "roughness": scenes.noise_texture(16, 2), "normal": None}
+        scenes.cornell_mesh_scene(a, 320, 180, mesh, tex)
+    else:
+        m = a.add_material(0, (0.5, 0.5, 0.5))
+        rr = np.random.RandomState(3)
+        for _ in range(5):
+            a.add_sphere((rr.rand(3) * 10).astype(np.float32), 0.5, m)     # loose objects in the world list
+        a.add_box((0, 0, 0), (1, 2, 3), m)                                  # a plain list of 12 triangles
+        lm = scenes.lathe_mesh(6, 4, seed=1)
+        a.add_mesh(scenes.VASE_MODEL, lm["positions"], lm["indices"], m, normals=lm["normals"], max_depth=1)
+        a.add_sphere((3.0, 3.0, 3.0), 1.0, m)
+    b = rt.Scene()
+    for k in range(a.flatten().n_materials):       # same materials, same indices
+        fa = a.get_flat()
+        kind, rgbp = int(fa["mat_kind"][k]), fa["mat_rgbp"][k]
+        if kind == 4:
+            td = b.add_texture(scenes.noise_texture(16, 1))
+            tr = b.add_texture(scenes.noise_texture(16, 2))
+            b.add_pbr(td, tr, -1)
+        else:
+            b.add_material(kind, rgbp[:3], float(rgbp[3]))
+    before = b.rng_floats(1)[0]
+    order = rebuild_through_group_calls(rt, a, b)
+    fa, fb = a.get_flat(), b.get_flat()
+    assert np.array_equal(fa["nodes"], fb["nodes"])                       # boxes, skip links, flags, run starts
+    ra, rb = fa["prim_refs"], fb["prim_refs"]
+    assert np.array_equal(ra >> 30, rb >> 30)                             # kinds and run ends
+    for kind in (0, 1):
+        sel = ((rb >> 30) & 1) == kind
+        assert np.array_equal(np.asarray(order[kind])[rb[sel] & 0x3FFFFFFF], ra[sel] & 0x3FFFFFFF)
+    # the generator was not touched: the next draw is the second value of a fresh stream
+    fresh = rt.Scene().rng_floats(2)
+    assert before == fresh[0] and b.rng_floats(1)[0] == fresh[1]
+
+
+def test_group_calls_must_balance(rt):
+    s = rt.Scene()
+    with pytest.raises(rt.RtError):
+        s.end_group()
+    s.begin_list()
+    s.add_sphere((0, 0, 0), 1.0, s.add_material(0, (0.5, 0.5, 0.5)))
+    with pytest.raises(rt.RtError):
+        s.flatten()
+    with pytest.raises(rt.RtError):
+        s.wrap_bvh()
+    s.end_group()
+    assert s.flatten().n_spheres == 1
