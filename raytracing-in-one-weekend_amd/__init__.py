@@ -56,6 +56,8 @@ SYMBOLS = {
     "rt_scene_add_material": (_I, [_VP, _I, _F, _F, _F, _F]),
     "rt_scene_add_texture_rgb8": (_I, [_VP, _I, _I, _VP]),
     "rt_texture_lut256": (_I, [_VP]),
+    "rt_scene_add_texture_file": (_I, [_VP, C.c_char_p]),
+    "rt_image_decode": (_I, [_VP, C.c_size_t, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), _VP, C.c_size_t]),
     "rt_scene_add_material_pbr": (_I, [_VP, _I, _I, _I]),
     "rt_scene_add_sphere": (_I, [_VP, _F, _F, _F, _F, _I]),
     "rt_scene_add_triangle": (_I, [_VP, _VP, _VP, _VP, _I]),
@@ -172,6 +174,9 @@ class Scene:
         assert a.ndim == 3 and a.shape[2] == 3
         return _check(lib.rt_scene_add_texture_rgb8(self.h, a.shape[1], a.shape[0], _p(a)))
 
+    def add_texture_file(self, path):
+        return _check(lib.rt_scene_add_texture_file(self.h, os.fsencode(path)))
+
     def add_pbr(self, tex_diffuse, tex_roughness=-1, tex_normal=-1):
         return _check(lib.rt_scene_add_material_pbr(self.h, tex_diffuse, tex_roughness, tex_normal))
 
@@ -287,6 +292,16 @@ def texture_lut():
     """The byte -> float map applied to texture channels (stbi_loadf's)."""
     out = np.zeros(256, np.float32)
     _check(lib.rt_texture_lut256(_p(out)))
+    return out
+
+
+def image_decode(file_bytes):
+    """Decodes a baseline JPEG or non-interlaced PNG: HxWxC uint8, C as stored in the file."""
+    buf = np.frombuffer(bytes(file_bytes), np.uint8)
+    w, h, c = C.c_int(), C.c_int(), C.c_int()
+    _check(lib.rt_image_decode(_p(buf), buf.size, C.byref(w), C.byref(h), C.byref(c), None, 0))
+    out = np.zeros((h.value, w.value, c.value), np.uint8)
+    _check(lib.rt_image_decode(_p(buf), buf.size, C.byref(w), C.byref(h), C.byref(c), _p(out), out.size))
     return out
 
 

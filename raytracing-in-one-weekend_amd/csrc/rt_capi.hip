@@ -14,6 +14,7 @@
 
 #include "../../include/rtiow_hip.h"
 #include "host_scene.h"
+#include "image_decode.h"
 #include "rt_device.h"
 
 namespace rt {
@@ -275,6 +276,49 @@ int rt_texture_lut256(float* out256) {
     for (int i = 0; i < 256; i++) out256[i] = (float)(std::pow(i / 255.0f, 2.2f) * 1.0f);
     return RT_OK;
 }
+static bool readWholeFile(const char* path, std::vector<uint8_t>* out) {
+    FILE* f = std::fopen(path, "rb");
+    if (!f) return false;
+    std::fseek(f, 0, SEEK_END);
+    const long n = std::ftell(f);
+    std::fseek(f, 0, SEEK_SET);
+    bool ok = n >= 0;
+    if (ok) {
+        out->resize((size_t)n);
+        ok = n == 0 || std::fread(out->data(), 1, (size_t)n, f) == (size_t)n;
+    }
+    std::fclose(f);
+    return ok;
+}
+
+int rt_image_decode(const uint8_t* file_bytes, size_t n_bytes, int* width, int* height, int* channels, uint8_t* pixels,
+                    size_t pixels_capacity) {
+    if (!file_bytes || !width || !height || !channels) return fail(RT_ERR_INVALID, "bad arguments");
+    rt::Image img;
+    std::string err;
+    if (!rt::decodeImage(file_bytes, n_bytes, &img, &err)) return fail(RT_ERR_INVALID, err);
+    *width = img.w;
+    *height = img.h;
+    *channels = img.channels;
+    if (pixels) {
+        if (pixels_capacity < img.px.size()) return fail(RT_ERR_LIMIT, "pixel buffer too small");
+        std::memcpy(pixels, img.px.data(), img.px.size());
+    }
+    return RT_OK;
+}
+
+int rt_scene_add_texture_file(rt_scene* s, const char* path) {
+    if (!s || !path) return fail(RT_ERR_INVALID, "bad arguments");
+    std::vector<uint8_t> bytes;
+    if (!readWholeFile(path, &bytes)) return fail(RT_ERR_INVALID, std::string("cannot read ") + path);
+    rt::Image img;
+    std::string err;
+    if (!rt::decodeImage(bytes.data(), bytes.size(), &img, &err)) return fail(RT_ERR_INVALID, std::string(path) + ": " + err);
+    std::vector<uint8_t> rgb;
+    rt::toRgb(img, &rgb);
+    return s->sc.addTexture(img.w, img.h, rgb.data());
+}
+
 int rt_scene_add_material_pbr(rt_scene* s, int td, int tr, int tn) {
     if (!s) return fail(RT_ERR_INVALID, "null scene");
     const int nt = (int)s->sc.textures.size();
