@@ -110,6 +110,21 @@ int rt_scene_add_mesh(rt_scene* s, const float* model16, int n_vertices, const f
  * Texture images are not decoded here; bind them through `material`. */
 int rt_scene_add_mesh_gltf(rt_scene* s, const float* model16, const char* gltf_path, int material, int max_depth);
 
+/* world.add(make_shared<Mesh>(model, file)) for a glTF 2.0 file, textures included: the whole of
+ * Mesh::Mesh (R/src/Core/Mesh.cpp:7-37) with the library's own glTF reader and image decoder in place of
+ * the importer and stb_image.  Every triangle-list primitive of every mesh, in the order processNode
+ * visits them (Mesh.cpp:39-52; node transforms are not applied there, nor here), becomes part of ONE
+ * triangle list with one mesh box and one BVHNode(triangles, 0, n, max_depth).
+ *   material < 0, per_primitive_materials = 0: the reference's rule (Mesh.cpp:56-104): one PBRMaterial
+ *     for the whole Mesh from the first base-colour texture met; metallic-roughness and normal maps
+ *     met from then on are attached to it (each image file is decoded once).
+ *   material >= 0: that material for every triangle; no image is read.
+ *   per_primitive_materials = 1 (beyond the reference, which shares one material per Mesh): every
+ *     primitive gets its own material -- PBR from its own textures, or Lambertian(baseColorFactor).
+ * Returns the id of the mesh's first triangle. */
+int rt_scene_add_mesh_file(rt_scene* s, const float* model16, const char* gltf_path, int max_depth, int material,
+                           int per_primitive_materials);
+
 /* Ingestion of a Hittable tree the caller has ALREADY built -- e.g. a Scene whose world holds a
  * BVHNode or a Mesh -- without re-building it (no random number is drawn, the caller's boxes are used
  * as they are).  Everything added between a begin call and the matching rt_scene_end_group() becomes a

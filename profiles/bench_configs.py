@@ -1,7 +1,7 @@
 """Timing of the other BASELINE.json configurations (parity-test cases, not the bench line):
 
   C1  cover scene 1200x675, 10 spp                      (the reference's CPU-runnable case)
-  C3  Cornell box + brass vase (glTF fixture, 2,760 triangles), three synthetic 4096^2 maps, 1080p 256 spp
+  C3  Cornell box + brass vase (glTF fixture, 2,760 triangles) with its three 4096^2 JPEG maps, 1080p 256 spp
   C4  cover scene 3840x2160, 1024 spp
   C5s instanced vases on a jittered grid, N triangles (default 1e6), 1080p 16 spp, unlimited-depth reference BVH
   C5  the same scene at 3840x2160, 256 spp
@@ -81,9 +81,8 @@ def c1():
 
 def c3():
     mesh = scenes.load_gltf_mesh(G)
-    tex = {"diffuse": scenes.noise_texture(4096, 1), "roughness": scenes.noise_texture(4096, 2),
-           "normal": scenes.noise_texture(4096, 3)}
-    run("C3 cornell+vase 1080p x256", lambda s: scenes.cornell_mesh_scene(s, 1920, 1080, mesh, tex),
+    tex = scenes.load_gltf_textures(G)     # the vase's own three 4096^2 JPEG maps
+    run("C3 cornell+vase (real 4096^2 maps) 1080p x256", lambda s: scenes.cornell_mesh_scene(s, 1920, 1080, mesh, tex),
         1920, 1080, 256, [100, 540, 900], oracle_spp=4)
 
 

@@ -64,6 +64,7 @@ SYMBOLS = {
     "rt_scene_add_box": (_I, [_VP, _VP, _VP, _I, _VP]),
     "rt_scene_add_mesh": (_I, [_VP, _VP, _I, _VP, _VP, _VP, _I, _VP, _I, _I]),
     "rt_scene_add_mesh_gltf": (_I, [_VP, _VP, C.c_char_p, _I, _I]),
+    "rt_scene_add_mesh_file": (_I, [_VP, _VP, C.c_char_p, _I, _I, _I]),
     "rt_scene_begin_bvh_node": (_I, [_VP, _VP]),
     "rt_scene_begin_mesh": (_I, [_VP, _VP]),
     "rt_scene_begin_list": (_I, [_VP]),
@@ -205,6 +206,12 @@ class Scene:
     def add_mesh_gltf(self, model, path, material, max_depth=10):
         m = _f32(model, 16)
         return _check(lib.rt_scene_add_mesh_gltf(self.h, _p(m), path.encode(), material, max_depth))
+
+    def add_mesh_file(self, model, path, max_depth=10, material=-1, per_primitive_materials=False):
+        """Mesh(model, path) for a glTF file, textures included (rt_scene_add_mesh_file)."""
+        m = _f32(model, 16)
+        return _check(lib.rt_scene_add_mesh_file(self.h, _p(m), os.fsencode(path), max_depth, material,
+                                                 1 if per_primitive_materials else 0))
 
     def begin_bvh_node(self, box6):
         b = _f32(box6, 6)

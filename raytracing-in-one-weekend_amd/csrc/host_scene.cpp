@@ -10,6 +10,7 @@
 #include <map>
 #include <thread>
 #include "host_scene.h"
+#include "image_decode.h"
 
 #include <algorithm>
 #include <cmath>
@@ -528,7 +529,7 @@ void Scene::wrapBvh() {
 
 // Mesh::Mesh + processMesh, R/src/Core/Mesh.cpp:7-37,106-208.
 int Scene::addMesh(const float* model16, int n_vertices, const float* positions, const float* normals, const float* uvs,
-                   int n_triangles, const uint32_t* indices, int mat, int max_depth) {
+                   int n_triangles, const uint32_t* indices, int mat, int max_depth, const int* tri_materials) {
     float inv[16];
     inverse4(model16, inv);
     Composite mesh;
@@ -557,7 +558,7 @@ int Scene::addMesh(const float* model16, int n_vertices, const float* positions,
                     nrm[3 * k + r] = (inv[r * 4 + 0] * n[0] + inv[r * 4 + 1] * n[1]) + inv[r * 4 + 2] * n[2];
             }
         }
-        int id = newTriangle(pos, nrm, uv, mat);
+        int id = newTriangle(pos, nrm, uv, tri_materials ? tri_materials[f] : mat);
         if (first < 0) first = id;
         tris.push_back({Obj::TRIANGLE, id});
         for (int a = 0; a < 3; a++) {  // Mesh.cpp:165-207
@@ -585,68 +586,86 @@ int Scene::addMesh(const float* model16, int n_vertices, const float* positions,
     return first;
 }
 
-// The subset of glTF 2.0 that the reference's one model needs: a single mesh primitive with
-// float POSITION / NORMAL / TEXCOORD_0 accessors and u16 or u32 indices in an external .bin.
-// The V texture coordinate is flipped (1 - v), which is what the importer used by the
-// reference hands to R/src/Core/Mesh.cpp:125-133 for glTF files.
-int Scene::addMeshGltf(const float* model16, const char* path, int mat, int max_depth, std::string* err) {
-    std::string text;
-    if (!readFile(path, &text)) {
-        *err = std::string("cannot read ") + path;
-        return -1;
+// glTF 2.0 reader (the job Assimp::Importer::ReadFile does for R/src/Core/Mesh.cpp:10-12): external
+// .bin buffers and image files, triangle-list primitives with float POSITION / NORMAL / TEXCOORD_0
+// and u8 / u16 / u32 (or no) indices.  Meshes are visited the way Mesh::processNode walks the importer's
+// node tree -- a node's meshes, then its children, from the scene's root nodes -- and, like the
+// reference, node transforms are NOT applied (processNode never reads aiNode::mTransformation; only
+// the caller's model matrix is).  The V texture coordinate is flipped (1 - v), which is what the
+// importer used by the reference hands to Mesh.cpp:125-133 for glTF files.
+namespace {
+
+struct GltfDoc {
+    JValue root;
+    std::string dir;
+    std::vector<std::string> blobs;
+    const JValue *meshes = nullptr, *accessors = nullptr, *views = nullptr, *nodes = nullptr, *materials = nullptr,
+                 *textures = nullptr, *images = nullptr;
+
+    static int asIndex(const JValue* v) {  // a JSON number used as an array index: -1 unless in int range
+        return v && v->t == JValue::NUM && v->num >= 0 && v->num < 2147483647.0 ? (int)v->num : -1;
     }
-    JParser jp(text);
-    JValue root = jp.parse();
-    if (!jp.ok || root.t != JValue::OBJ) {
-        *err = "malformed glTF JSON";
-        return -1;
+    static const JValue* at(const JValue* arr, int i) {
+        return arr && arr->t == JValue::ARR && i >= 0 && i < (int)arr->arr.size() ? &arr->arr[(size_t)i] : nullptr;
     }
-    const JValue *meshes = root.get("meshes"), *accessors = root.get("accessors"), *views = root.get("bufferViews"),
-                 *buffers = root.get("buffers");
-    if (!meshes || !accessors || !views || !buffers || meshes->arr.empty()) {
-        *err = "glTF lacks meshes/accessors/bufferViews/buffers";
-        return -1;
-    }
-    std::string dir(path);
-    size_t slash = dir.find_last_of('/');
-    dir = slash == std::string::npos ? std::string(".") : dir.substr(0, slash);
-    std::vector<std::string> blobs(buffers->arr.size());
-    for (size_t i = 0; i < buffers->arr.size(); i++) {
-        const JValue* uri = buffers->arr[i].get("uri");
-        if (!uri || !readFile(dir + "/" + uri->str, &blobs[i])) {
-            *err = "cannot read glTF buffer";
-            return -1;
+
+    bool open(const char* path, std::string* err) {
+        std::string text;
+        if (!readFile(path, &text)) {
+            *err = std::string("cannot read ") + path;
+            return false;
         }
+        JParser jp(text);
+        root = jp.parse();
+        if (!jp.ok || root.t != JValue::OBJ) {
+            *err = "malformed glTF JSON";
+            return false;
+        }
+        meshes = root.get("meshes");
+        accessors = root.get("accessors");
+        views = root.get("bufferViews");
+        nodes = root.get("nodes");
+        materials = root.get("materials");
+        textures = root.get("textures");
+        images = root.get("images");
+        const JValue* buffers = root.get("buffers");
+        if (!meshes || !accessors || !views || !buffers || meshes->t != JValue::ARR || accessors->t != JValue::ARR ||
+            views->t != JValue::ARR || buffers->t != JValue::ARR || meshes->arr.empty()) {
+            *err = "glTF lacks meshes/accessors/bufferViews/buffers";
+            return false;
+        }
+        dir = path;
+        const size_t slash = dir.find_last_of('/');
+        dir = slash == std::string::npos ? std::string(".") : dir.substr(0, slash);
+        blobs.resize(buffers->arr.size());
+        for (size_t i = 0; i < buffers->arr.size(); i++) {
+            const JValue* uri = buffers->arr[i].get("uri");
+            if (!uri || uri->t != JValue::STR || uri->str.compare(0, 5, "data:") == 0 || !readFile(dir + "/" + uri->str, &blobs[i])) {
+                *err = "cannot read glTF buffer (external .bin files only)";
+                return false;
+            }
+        }
+        return true;
     }
-    const JValue* prims = meshes->arr[0].get("primitives");
-    if (!prims || prims->arr.empty()) {
-        *err = "mesh without primitives";
-        return -1;
-    }
-    const JValue& prim = prims->arr[0];
-    const JValue* attrs = prim.get("attributes");
-    const JValue* idxAcc = prim.get("indices");
-    if (!attrs || !attrs->get("POSITION") || !idxAcc) {
-        *err = "primitive needs POSITION and indices";
-        return -1;
-    }
+
     struct View {
-        const char* data;
-        size_t count;
-        int comp;
-        size_t stride;
+        const char* data = nullptr;
+        size_t count = 0;
+        int comp = 0;
+        size_t stride = 0;
     };
-    auto view = [&](int acc, int ncomp, size_t compSize, View* out) -> bool {
-        if (acc < 0 || acc >= (int)accessors->arr.size()) return false;
-        const JValue& a = accessors->arr[acc];
-        const JValue *bv = a.get("bufferView"), *cnt = a.get("count"), *ct = a.get("componentType");
+    bool view(int acc, int ncomp, size_t compSize, View* out) const {
+        const JValue* a = at(accessors, acc);
+        if (!a) return false;
+        const JValue *bv = a->get("bufferView"), *cnt = a->get("count"), *ct = a->get("componentType");
         if (!bv || !cnt || !ct || bv->t != JValue::NUM || cnt->t != JValue::NUM || ct->t != JValue::NUM) return false;
-        if (!(bv->num >= 0) || bv->num >= (double)views->arr.size() || !(cnt->num >= 0) || cnt->num > 4e9) return false;
-        const JValue& v = views->arr[(size_t)bv->num];
-        const JValue *buf = v.get("buffer"), *off = v.get("byteOffset"), *st = v.get("byteStride");
+        if (!(cnt->num >= 0) || cnt->num > 4e9) return false;
+        const JValue* v = at(views, asIndex(bv));
+        if (!v) return false;
+        const JValue *buf = v->get("buffer"), *off = v->get("byteOffset"), *st = v->get("byteStride");
         const double bufIdx = buf ? buf->num : 0.0;
         if (!(bufIdx >= 0) || bufIdx >= (double)blobs.size()) return false;
-        const double o1 = off ? off->num : 0.0, o2 = a.get("byteOffset") ? a.get("byteOffset")->num : 0.0;
+        const double o1 = off ? off->num : 0.0, o2 = a->get("byteOffset") ? a->get("byteOffset")->num : 0.0;
         const double strideNum = st ? st->num : (double)(ncomp * compSize);
         if (!(o1 >= 0) || !(o2 >= 0) || o1 > 4e9 || o2 > 4e9 || !(strideNum >= (double)(ncomp * compSize)) || strideNum > 4e9)
             return false;
@@ -658,62 +677,240 @@ int Scene::addMeshGltf(const float* model16, const char* path, int mat, int max_
         if (offset + (out->count ? (out->count - 1) * out->stride + ncomp * compSize : 0) > blob.size()) return false;
         out->data = blob.data() + offset;
         return true;
+    }
+
+    // Meshes in the order Mesh::processNode reaches them (R/src/Core/Mesh.cpp:39-52).
+    void meshOrder(std::vector<int>* out) const {
+        std::vector<int> roots;
+        const JValue* scenes = root.get("scenes");
+        const JValue* sc = at(scenes, std::max(0, asIndex(root.get("scene"))));
+        if (sc && sc->get("nodes") && sc->get("nodes")->t == JValue::ARR)
+            for (const JValue& r : sc->get("nodes")->arr) roots.push_back(asIndex(&r));
+        std::vector<char> seen(nodes && nodes->t == JValue::ARR ? nodes->arr.size() : 0, 0);
+        std::vector<int> stack(roots.rbegin(), roots.rend());
+        while (!stack.empty()) {
+            const int n = stack.back();
+            stack.pop_back();
+            const JValue* node = at(nodes, n);
+            if (!node || seen[(size_t)n]) continue;  // a node reachable twice (or a cycle) is visited once
+            seen[(size_t)n] = 1;
+            const int m = asIndex(node->get("mesh"));
+            if (at(meshes, m)) out->push_back(m);
+            const JValue* kids = node->get("children");
+            if (kids && kids->t == JValue::ARR)
+                for (auto it = kids->arr.rbegin(); it != kids->arr.rend(); ++it) stack.push_back(asIndex(&*it));
+        }
+        if (out->empty())  // no scene graph: every mesh, in file order
+            for (size_t m = 0; m < meshes->arr.size(); m++) out->push_back((int)m);
+    }
+
+    // File name of the image behind `material.<slot>` (slot inside pbrMetallicRoughness when pbr is
+    // set), or "" when the material has no such texture.
+    std::string textureFile(const JValue* material, const char* slot, bool pbr) const {
+        if (!material) return "";
+        const JValue* holder = pbr ? material->get("pbrMetallicRoughness") : material;
+        const JValue* ref = holder ? holder->get(slot) : nullptr;
+        const JValue* tex = ref ? at(textures, asIndex(ref->get("index"))) : nullptr;
+        const JValue* image = tex ? at(images, asIndex(tex->get("source"))) : nullptr;
+        const JValue* uri = image ? image->get("uri") : nullptr;
+        return uri && uri->t == JValue::STR && uri->str.compare(0, 5, "data:") != 0 ? uri->str : "";
+    }
+};
+
+}  // namespace
+
+int Scene::textureFromFile(const std::string& path, std::string* err) {
+    std::string bytes;
+    if (!readFile(path, &bytes)) {
+        *err = "cannot read " + path;
+        return -1;
+    }
+    Image img;
+    std::string why;
+    if (!decodeImage(reinterpret_cast<const uint8_t*>(bytes.data()), bytes.size(), &img, &why)) {
+        *err = path + ": " + why;
+        return -1;
+    }
+    std::vector<uint8_t> rgb;
+    toRgb(img, &rgb);
+    return addTexture(img.w, img.h, rgb.data());
+}
+
+// Mesh::Mesh(model, location) (R/src/Core/Mesh.cpp:7-37) for a glTF file.
+//   material >= 0: every triangle gets that material and no image is read (textures bound by the caller).
+//   material < 0, per_primitive = false: the reference's rule (Mesh.cpp:56-104) -- ONE PBRMaterial for
+//     the whole Mesh, created from the first primitive whose material has a base-colour texture; the
+//     metallic-roughness and normal textures of the primitives met from then on are attached to it.
+//   per_primitive = true (beyond the reference): every primitive gets a material of its own -- PBR with
+//     its own three textures when it has a base-colour texture, else Lambertian with its baseColorFactor.
+// first_primitive_only restricts the mesh to the first primitive of the first mesh.
+int Scene::addMeshGltf(const float* model16, const char* path, int material, int max_depth, bool per_primitive,
+                       bool first_primitive_only, std::string* err) {
+    GltfDoc g;
+    if (!g.open(path, err)) return -1;
+    std::vector<int> order;
+    if (first_primitive_only)
+        order.push_back(0);
+    else
+        g.meshOrder(&order);
+
+    std::vector<float> P, N, T;
+    std::vector<uint32_t> I;
+    std::vector<int> triMat;
+    bool anyN = false, anyT = false, allN = true, allT = true;
+    std::map<std::string, int> loaded;  // image file -> texture index (each file is decoded once)
+    auto texture = [&](const std::string& file) -> int {
+        if (file.empty()) return -1;
+        auto it = loaded.find(file);
+        if (it != loaded.end()) return it->second;
+        const int t = textureFromFile(g.dir + "/" + file, err);
+        if (t >= 0) loaded[file] = t;
+        return t;
     };
-    // a JSON number used as an array index: -1 unless it is a number in int range
-    auto asIndex = [](const JValue* v) -> int {
-        return v && v->t == JValue::NUM && v->num >= 0 && v->num < 2147483647.0 ? (int)v->num : -1;
-    };
-    View vp{}, vn{}, vt{}, vi{};
-    if (!view(asIndex(attrs->get("POSITION")), 3, 4, &vp) || vp.comp != 5126) {
-        *err = "bad POSITION accessor";
-        return -1;
-    }
-    // optional attributes: absent is fine, present but unreadable is an error
-    const bool hasN = attrs->get("NORMAL") != nullptr, hasT = attrs->get("TEXCOORD_0") != nullptr;
-    if ((hasN && !(view(asIndex(attrs->get("NORMAL")), 3, 4, &vn) && vn.comp == 5126)) ||
-        (hasT && !(view(asIndex(attrs->get("TEXCOORD_0")), 2, 4, &vt) && vt.comp == 5126))) {
-        *err = "bad NORMAL / TEXCOORD_0 accessor";
-        return -1;
-    }
-    int idxComp = 0;
-    const int idxAccI = asIndex(idxAcc);
-    if (idxAccI >= 0 && idxAccI < (int)accessors->arr.size()) {
-        const JValue* ct = accessors->arr[(size_t)idxAccI].get("componentType");
-        if (ct && ct->t == JValue::NUM) idxComp = (int)ct->num;
-    }
-    size_t idxSize = idxComp == 5123 ? 2 : (idxComp == 5125 ? 4 : 0);
-    if (!idxSize || !view(idxAccI, 1, idxSize, &vi)) {
-        *err = "bad index accessor";
-        return -1;
-    }
-    size_t nv = vp.count;
-    std::vector<float> P(nv * 3), N, T;
-    for (size_t i = 0; i < nv; i++) std::memcpy(&P[3 * i], vp.data + i * vp.stride, 12);
-    if (hasN && vn.count == nv) {
-        N.resize(nv * 3);
-        for (size_t i = 0; i < nv; i++) std::memcpy(&N[3 * i], vn.data + i * vn.stride, 12);
-    }
-    if (hasT && vt.count == nv) {
-        T.resize(nv * 2);
-        for (size_t i = 0; i < nv; i++) {
-            float uvv[2];
-            std::memcpy(uvv, vt.data + i * vt.stride, 8);
-            T[2 * i] = uvv[0];
-            T[2 * i + 1] = 1.0f - uvv[1];
+    int shared = material;  // the one material of the reference's rule, once it exists
+    std::string sharedR, sharedN;
+    for (int m : order) {
+        const JValue* prims = g.meshes->arr[(size_t)m].get("primitives");
+        if (!prims || prims->t != JValue::ARR || prims->arr.empty()) {
+            *err = "mesh without primitives";
+            return -1;
+        }
+        for (size_t pi = 0; pi < prims->arr.size(); pi++) {
+            if (first_primitive_only && pi > 0) break;
+            const JValue& prim = prims->arr[pi];
+            const JValue* attrs = prim.get("attributes");
+            if (!attrs || !attrs->get("POSITION")) {
+                *err = "primitive needs POSITION";
+                return -1;
+            }
+            const JValue* mode = prim.get("mode");
+            if (mode && GltfDoc::asIndex(mode) != 4) {
+                *err = "only triangle-list primitives (mode 4) are supported";
+                return -1;
+            }
+            GltfDoc::View vp, vn, vt, vi;
+            if (!g.view(GltfDoc::asIndex(attrs->get("POSITION")), 3, 4, &vp) || vp.comp != 5126) {
+                *err = "bad POSITION accessor";
+                return -1;
+            }
+            // optional attributes: absent is fine, present but unreadable is an error
+            const bool hasN = attrs->get("NORMAL") != nullptr, hasT = attrs->get("TEXCOORD_0") != nullptr;
+            if ((hasN && !(g.view(GltfDoc::asIndex(attrs->get("NORMAL")), 3, 4, &vn) && vn.comp == 5126 && vn.count == vp.count)) ||
+                (hasT && !(g.view(GltfDoc::asIndex(attrs->get("TEXCOORD_0")), 2, 4, &vt) && vt.comp == 5126 && vt.count == vp.count))) {
+                *err = "bad NORMAL / TEXCOORD_0 accessor";
+                return -1;
+            }
+            const size_t base = P.size() / 3, nv = vp.count;
+            if (base + nv > 0x7FFFFFFFu) {
+                *err = "too many vertices";
+                return -1;
+            }
+            P.resize((base + nv) * 3);
+            N.resize((base + nv) * 3, 0.0f);
+            T.resize((base + nv) * 2, 0.0f);
+            for (size_t i = 0; i < nv; i++) std::memcpy(&P[3 * (base + i)], vp.data + i * vp.stride, 12);
+            if (hasN)
+                for (size_t i = 0; i < nv; i++) std::memcpy(&N[3 * (base + i)], vn.data + i * vn.stride, 12);
+            if (hasT)
+                for (size_t i = 0; i < nv; i++) {
+                    float uvv[2];
+                    std::memcpy(uvv, vt.data + i * vt.stride, 8);
+                    T[2 * (base + i)] = uvv[0];
+                    T[2 * (base + i) + 1] = 1.0f - uvv[1];
+                }
+            anyN = anyN || hasN;
+            anyT = anyT || hasT;
+            allN = allN && hasN;
+            allT = allT && hasT;
+            const size_t firstIndex = I.size();
+            if (prim.get("indices")) {
+                const int idxAcc = GltfDoc::asIndex(prim.get("indices"));
+                const JValue* acc = GltfDoc::at(g.accessors, idxAcc);
+                const JValue* ct = acc ? acc->get("componentType") : nullptr;
+                const int idxComp = ct && ct->t == JValue::NUM ? (int)ct->num : 0;
+                const size_t idxSize = idxComp == 5121 ? 1 : (idxComp == 5123 ? 2 : (idxComp == 5125 ? 4 : 0));
+                if (!idxSize || !g.view(idxAcc, 1, idxSize, &vi)) {
+                    *err = "bad index accessor";
+                    return -1;
+                }
+                for (size_t i = 0; i < vi.count; i++) {
+                    uint32_t v = 0;
+                    std::memcpy(&v, vi.data + i * vi.stride, idxSize);  // little-endian host
+                    if (v >= nv) {
+                        *err = "index out of range in glTF mesh";
+                        return -1;
+                    }
+                    I.push_back((uint32_t)base + v);
+                }
+            } else {
+                for (size_t i = 0; i < nv; i++) I.push_back((uint32_t)(base + i));
+            }
+            const size_t nTri = (I.size() - firstIndex) / 3;
+            I.resize(firstIndex + nTri * 3);
+
+            // ---- material of this primitive
+            const JValue* mat = GltfDoc::at(g.materials, GltfDoc::asIndex(prim.get("material")));
+            int use = material;
+            if (material < 0) {
+                const std::string fd = g.textureFile(mat, "baseColorTexture", true);
+                const std::string fr = g.textureFile(mat, "metallicRoughnessTexture", true);
+                const std::string fn = g.textureFile(mat, "normalTexture", false);
+                if (per_primitive) {
+                    if (!fd.empty()) {
+                        const int td = texture(fd), tr = texture(fr), tn = texture(fn);
+                        if (td < 0 || (!fr.empty() && tr < 0) || (!fn.empty() && tn < 0)) return -1;
+                        use = addPbr(td, tr, tn);
+                    } else {
+                        float rgb[3] = {1.0f, 1.0f, 1.0f};  // glTF's default baseColorFactor
+                        const JValue* pbr = mat ? mat->get("pbrMetallicRoughness") : nullptr;
+                        const JValue* f = pbr ? pbr->get("baseColorFactor") : nullptr;
+                        if (f && f->t == JValue::ARR && f->arr.size() >= 3)
+                            for (int k = 0; k < 3; k++) rgb[k] = (float)f->arr[(size_t)k].num;
+                        use = addMaterial(0, rgb[0], rgb[1], rgb[2], 0.0f);
+                    }
+                } else {
+                    // Mesh.cpp:58-104: a texture file that was already loaded is not loaded (or attached) again
+                    if (!fd.empty() && shared < 0) {
+                        const int td = texture(fd);
+                        if (td < 0) return -1;
+                        shared = addPbr(td, -1, -1);
+                    }
+                    if (shared >= 0 && !fr.empty() && !loaded.count(fr)) {
+                        const int tr = texture(fr);
+                        if (tr < 0) return -1;
+                        materials[(size_t)shared].tex_r = tr;
+                    }
+                    if (shared >= 0 && !fn.empty() && !loaded.count(fn)) {
+                        const int tn = texture(fn);
+                        if (tn < 0) return -1;
+                        materials[(size_t)shared].tex_n = tn;
+                    }
+                    use = -2;  // resolved after the loop: every triangle shares the one material
+                }
+            }
+            triMat.insert(triMat.end(), nTri, use);
         }
     }
-    std::vector<uint32_t> I(vi.count);
-    for (size_t i = 0; i < vi.count; i++) {
-        if (idxSize == 2) {
-            uint16_t v;
-            std::memcpy(&v, vi.data + i * vi.stride, 2);
-            I[i] = v;
-        } else {
-            std::memcpy(&I[i], vi.data + i * vi.stride, 4);
+    if (material < 0 && !per_primitive) {
+        if (shared < 0) {
+            // the reference would leave matPtr null here and crash on the first hit
+            *err = "no material of this glTF file has a base-colour texture; pass a material";
+            return -1;
         }
+        for (int& t : triMat) t = shared;
     }
-    int r = addMesh(model16, (int)nv, P.data(), N.empty() ? nullptr : N.data(), T.empty() ? nullptr : T.data(),
-                    (int)(I.size() / 3), I.data(), mat, max_depth);
+    if (I.empty()) {
+        *err = "glTF mesh without triangles";
+        return -1;
+    }
+    // Mesh.cpp:122-142: default texture coordinates / zero normals apply per aiMesh; with several
+    // primitives a missing attribute is therefore only representable when all of them lack it
+    if ((anyN && !allN) || (anyT && !allT)) {
+        *err = "primitives of one file must agree on having NORMAL / TEXCOORD_0";
+        return -1;
+    }
+    int r = addMesh(model16, (int)(P.size() / 3), P.data(), anyN ? N.data() : nullptr, anyT ? T.data() : nullptr,
+                    (int)(I.size() / 3), I.data(), triMat[0], max_depth, triMat.data());
     if (r < 0) *err = "index out of range in glTF mesh";
     return r;
 }

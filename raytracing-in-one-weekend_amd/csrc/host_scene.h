@@ -114,8 +114,10 @@ public:
     int addTriangle(const float* pos9, const float* nrm9, const float* uv6, int mat);
     int addBox(const float* p0, const float* p1, int mat, const float* model16);
     int addMesh(const float* model16, int n_vertices, const float* positions, const float* normals, const float* uvs,
-                int n_triangles, const uint32_t* indices, int mat, int max_depth);
-    int addMeshGltf(const float* model16, const char* path, int mat, int max_depth, std::string* err);
+                int n_triangles, const uint32_t* indices, int mat, int max_depth, const int* tri_materials = nullptr);
+    int addMeshGltf(const float* model16, const char* path, int material, int max_depth, bool per_primitive,
+                    bool first_primitive_only, std::string* err);
+    int textureFromFile(const std::string& path, std::string* err);
     // Ingestion of a tree the caller has already built (no random numbers are drawn): objects added
     // between beginGroup() and endGroup() become the children, in order, of one composite.
     // boxed = true: the caller's box is tested first, then the children are scanned with the running

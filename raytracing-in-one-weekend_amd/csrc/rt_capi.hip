@@ -349,7 +349,17 @@ int rt_scene_add_mesh(rt_scene* s, const float* model16, int n_vertices, const f
 int rt_scene_add_mesh_gltf(rt_scene* s, const float* model16, const char* gltf_path, int material, int max_depth) {
     if (!matOk(s, material) || !model16 || !gltf_path) return fail(RT_ERR_INVALID, "bad mesh arguments");
     std::string err;
-    int r = s->sc.addMeshGltf(model16, gltf_path, material, max_depth, &err);
+    int r = s->sc.addMeshGltf(model16, gltf_path, material, max_depth, false, true, &err);
+    if (r < 0) return fail(RT_ERR_INVALID, err);
+    return r;
+}
+int rt_scene_add_mesh_file(rt_scene* s, const float* model16, const char* gltf_path, int max_depth, int material,
+                           int per_primitive_materials) {
+    if (!s || !model16 || !gltf_path) return fail(RT_ERR_INVALID, "bad mesh arguments");
+    if (material >= 0 && !matOk(s, material)) return fail(RT_ERR_INVALID, "material index out of range");
+    std::string err;
+    int r = s->sc.addMeshGltf(model16, gltf_path, material < 0 ? -1 : material, max_depth, per_primitive_materials != 0,
+                              false, &err);
     if (r < 0) return fail(RT_ERR_INVALID, err);
     return r;
 }

@@ -140,6 +140,30 @@ def noise_texture(size, seed, octaves=4):
     return np.clip(out * 255.0 + 0.5, 0, 255).astype(np.uint8)
 
 
+def load_gltf_textures(path):
+    """The three maps a glTF file's first material binds, decoded with the library's own JPEG / PNG
+    decoder: dict(diffuse, roughness, normal) of HxWx3 uint8 arrays (None where the file has none),
+    keyed the way Mesh::processMesh uses them (R/src/Core/Mesh.cpp:56-104: base colour -> diffuse,
+    metallic-roughness -> roughness, normal -> normal)."""
+    import json
+    import os
+    from . import image_decode
+    g = json.load(open(path))
+    base = os.path.dirname(path)
+    mat = g["materials"][0]
+    pbr = mat.get("pbrMetallicRoughness", {})
+
+    def tex(ref):
+        if not ref:
+            return None
+        uri = g["images"][g["textures"][ref["index"]]["source"]]["uri"]
+        img = image_decode(open(os.path.join(base, uri), "rb").read())
+        return np.ascontiguousarray(np.repeat(img, 3, axis=2) if img.shape[2] < 3 else img[:, :, :3])
+
+    return {"diffuse": tex(pbr.get("baseColorTexture")), "roughness": tex(pbr.get("metallicRoughnessTexture")),
+            "normal": tex(mat.get("normalTexture"))}
+
+
 def load_gltf_mesh(path):
     """Positions / normals / flipped texture coordinates / indices of the first primitive of a
     glTF 2.0 file with an external buffer: what the reference's importer hands to

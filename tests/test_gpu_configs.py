@@ -214,3 +214,35 @@ def test_far_camera_rays_take_the_reference_walk(rt, orc, gpu_ctx):
         assert np.array_equal(k1, k2) and np.array_equal(p1, p2) and np.array_equal(bits(t1), bits(t2)), dist
         seen_far += int((k1 >= 0).sum())
     assert seen_far > 1000
+
+
+def test_cornell_vase_with_its_real_maps(rt, orc, scenes, gpu_ctx):
+    """The Cornell box with the brass vase as the application sets it up (R/src/RaytracingApplication.cpp:
+    296-346), textured with the vase's own three 4096x4096 JPEG maps decoded by the library (bytes equal
+    stb_image's, tests/test_image_decode.py): image equal to the oracle's bit for bit, and the one-call
+    loader (rt_scene_add_mesh_file) renders the same image."""
+    w, h, spp = 320, 180, 2
+    mesh = scenes.load_gltf_mesh(VASE)
+    tex = scenes.load_gltf_textures(VASE)
+    assert all(tex[k].shape == (4096, 4096, 3) for k in ("diffuse", "roughness", "normal"))
+    a, b = rt.Scene(), orc.OracleScene()
+    scenes.cornell_mesh_scene(a, w, h, mesh, tex)
+    scenes.cornell_mesh_scene(b, w, h, mesh, tex)
+    gpu_ctx.upload_scene(a)
+    gpu_ctx.set_target(w, h)
+    gpu_ctx.render(0, spp, 50)
+    gpu_ctx.sync()
+    got = gpu_ctx.read_accum()
+    want, _, cnt = b.render(w, h, 0, spp, 50, rng_mode=1, order=1, threads=16, want_counters=True)
+    assert np.array_equal(bits(got[..., :3]), bits(want[..., :3]))
+    assert cnt["scatter_pbr"] > 1000 and got[..., :3].max() > 0
+    c = rt.Scene()
+    c.cornell_box()
+    c.add_mesh_file(scenes.VASE_MODEL, VASE)
+    c.set_camera((278.0, 278.0, -800.0), (278.0, 278.0, 0.0), (0.0, 1.0, 0.0), 40.0, scenes.aspect_ratio(w, h), 0.0, 10.0)
+    c.set_background((0.0, 0.0, 0.0))
+    gpu_ctx.upload_scene(c)
+    gpu_ctx.set_target(w, h)
+    gpu_ctx.render(0, spp, 50)
+    gpu_ctx.sync()
+    assert np.array_equal(bits(gpu_ctx.read_accum()), bits(got))

@@ -87,3 +87,113 @@ def test_brass_vase_maps_decode_to_stb_images_bytes(rt):
         xy = z["xy"][k]
         assert np.array_equal(img[xy[:, 1], xy[:, 0]], z["rgb8"][k])
         assert hashlib.sha256(img.tobytes()).hexdigest() == m["sha256_rgb8"], key   # all 50 MB, byte for byte
+
+
+VASE_GLTF = os.path.join(HERE, "golden", "brass_vase", "brass_vase_04_4k.gltf")
+
+
+def test_mesh_file_loads_the_vase_with_its_three_maps(rt, scenes):
+    """rt_scene_add_mesh_file = Mesh(model, path): geometry, the three JPEG maps the glTF names and the
+    one PBR material the reference builds from them (R/src/Core/Mesh.cpp:56-104) -- the same scene as
+    putting it together by hand from the separate calls."""
+    a = rt.Scene()
+    first = a.add_mesh_file(scenes.VASE_MODEL, VASE_GLTF)
+    fa = a.get_flat()
+    assert first == 0 and fa["info"].n_triangles == 2760 and fa["info"].n_textures == 3 and fa["info"].n_materials == 1
+    assert fa["mat_kind"][0] == rt.MAT_PBR and (fa["tri_mat"] == 0).all()
+    b = rt.Scene()
+    tex = os.path.join(os.path.dirname(VASE_GLTF), "textures")
+    td = b.add_texture_file(os.path.join(tex, "brass_vase_04_diff_4k.jpg"))     # baseColorTexture
+    tr = b.add_texture_file(os.path.join(tex, "brass_vase_04_arm_4k.jpg"))      # metallicRoughnessTexture
+    tn = b.add_texture_file(os.path.join(tex, "brass_vase_04_nor_gl_4k.jpg"))   # normalTexture
+    b.add_mesh_gltf(scenes.VASE_MODEL, VASE_GLTF, b.add_pbr(td, tr, tn))
+    fb = b.get_flat()
+    for k in ("nodes", "prim_refs", "tri_pos", "tri_normal", "tri_uv", "tri_mat", "mat_kind"):
+        assert np.array_equal(fa[k], fb[k]), k
+    # the textures the maps decode to are the reference decoder's (checked whole in
+    # test_brass_vase_maps_decode_to_stb_images_bytes where the reference tree exists; here by sample)
+    z = np.load(os.path.join(HERE, "golden", "stb_vase_texels.npz"))
+    img = rt.image_decode(open(os.path.join(tex, "brass_vase_04_diff_4k.jpg"), "rb").read())
+    xy = z["xy"][0]
+    assert np.array_equal(img[xy[:, 1], xy[:, 0]], z["rgb8"][0])
+
+
+def write_two_mesh_gltf(tmp_path, with_texture=True):
+    """A hand-made file: root node 0 (mesh 1) with child node 1 (mesh 0); mesh 0 has two primitives
+    (materials 0 and 1), mesh 1 one primitive (material 1); u8, u16 and no indices."""
+    import struct
+    quad = np.float32([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0]])
+    nrm = np.float32([[0, 0, 1]] * 4)
+    uv = np.float32([[0, 0], [1, 0], [1, 1], [0, 1]])
+    blob = bytearray()
+
+    def put(arr):
+        off = len(blob)
+        blob.extend(arr.tobytes())
+        while len(blob) % 4:
+            blob.append(0)
+        return off, len(arr.tobytes())
+
+    views, accs = [], []
+
+    def acc(arr, ctype, typ):
+        off, n = put(arr)
+        views.append({"buffer": 0, "byteOffset": off, "byteLength": n})
+        accs.append({"bufferView": len(views) - 1, "componentType": ctype, "count": len(arr), "type": typ})
+        return len(accs) - 1
+
+    prims = []
+    for k, (shift, idx) in enumerate(((0.0, np.uint8([0, 1, 2, 0, 2, 3])), (2.0, np.uint16([0, 1, 2, 0, 2, 3])), (4.0, None))):
+        pos = quad + np.float32([shift, 0, 0])
+        if idx is None:
+            pos, n2, uv2 = pos[[0, 1, 2, 0, 2, 3]], nrm[[0, 1, 2, 0, 2, 3]], uv[[0, 1, 2, 0, 2, 3]]
+        else:
+            n2, uv2 = nrm, uv
+        p = {"attributes": {"POSITION": acc(pos, 5126, "VEC3"), "NORMAL": acc(n2, 5126, "VEC3"),
+                            "TEXCOORD_0": acc(uv2, 5126, "VEC2")}, "material": [0, 1, 1][k]}
+        if idx is not None:
+            p["indices"] = acc(idx, 5121 if idx.dtype == np.uint8 else 5123, "SCALAR")
+        prims.append(p)
+    g = {"asset": {"version": "2.0"}, "scene": 0, "scenes": [{"nodes": [0]}],
+         "nodes": [{"mesh": 1, "children": [1]}, {"mesh": 0, "translation": [100, 0, 0]}],
+         "meshes": [{"primitives": prims[:2]}, {"primitives": prims[2:]}],
+         "materials": [{"pbrMetallicRoughness": {"baseColorFactor": [0.8, 0.1, 0.2, 1.0]}},
+                       {"pbrMetallicRoughness": ({"baseColorTexture": {"index": 0}} if with_texture else {})}],
+         "textures": [{"source": 0}], "images": [{"uri": "tex.png"}],
+         "buffers": [{"uri": "data.bin", "byteLength": len(blob)}], "bufferViews": views, "accessors": accs}
+    d = tmp_path / "two"
+    d.mkdir(parents=True)
+    json.dump(g, open(d / "two.gltf", "w"))
+    open(d / "data.bin", "wb").write(bytes(blob))
+    import shutil
+    shutil.copy(os.path.join(IMG, "rgb8_31x17.png"), d / "tex.png")
+    return str(d / "two.gltf")
+
+
+def test_multi_primitive_file_in_both_material_modes(rt, tmp_path):
+    path = write_two_mesh_gltf(tmp_path)
+    # the reference's rule: one shared PBR material from the first base-colour texture met
+    a = rt.Scene()
+    a.add_mesh_file(rt.IDENTITY, path, max_depth=-1)
+    fa = a.get_flat()
+    assert fa["info"].n_triangles == 6 and fa["info"].n_materials == 1 and fa["info"].n_textures == 1
+    assert fa["mat_kind"][0] == rt.MAT_PBR and (fa["tri_mat"] == 0).all()
+    # visiting order: the root node's mesh (mesh 1, x in [4, 5]) first, then the child's (mesh 0); the
+    # node's translation is NOT applied (the reference never reads node transforms)
+    x0 = fa["tri_pos"][:, 0::3].min(axis=1)
+    assert list(x0) == [4.0, 4.0, 0.0, 0.0, 2.0, 2.0]
+    # per-primitive materials (beyond the reference)
+    b = rt.Scene()
+    b.add_mesh_file(rt.IDENTITY, path, max_depth=-1, per_primitive_materials=True)
+    fb = b.get_flat()
+    assert fb["info"].n_materials == 3 and fb["info"].n_textures == 1          # the image is decoded once
+    assert list(fb["mat_kind"]) == [rt.MAT_PBR, rt.MAT_LAMBERTIAN, rt.MAT_PBR]
+    assert np.allclose(fb["mat_rgbp"][1][:3], [0.8, 0.1, 0.2])
+    assert list(fb["tri_mat"]) == [0, 0, 1, 1, 2, 2]
+    # a caller's material for everything: no image is read
+    c = rt.Scene()
+    c.add_mesh_file(rt.IDENTITY, path, material=c.add_material(0, (0.5, 0.5, 0.5)))
+    assert c.flatten().n_textures == 0 and (c.get_flat()["tri_mat"] == 0).all()
+    # no base-colour texture anywhere: the reference would dereference a null material; refused here
+    with pytest.raises(rt.RtError):
+        rt.Scene().add_mesh_file(rt.IDENTITY, write_two_mesh_gltf(tmp_path / "x", with_texture=False))
