@@ -216,6 +216,19 @@ int rt_set_stream(rt_context* ctx, void* hip_stream);
  * guard test of the winner fails; both settings return identical hits.  Applies to later calls. */
 int rt_set_reference_traversal(rt_context* ctx, int on);
 
+/* With on = 1, later rt_upload_scene() calls build the search structure ON THE DEVICE (a linear BVH over
+ * Morton-sorted primitives, csrc/device_bvh.hip) instead of the host's surface-area-heuristic build: far
+ * faster to build for million-triangle scenes, somewhat more box tests per ray.  No counterpart in the
+ * reference; the reference-order tree (BVHNode's constructor, R/src/AccelerationStructures/Bvh.h:18-78,
+ * sequential by its use of one random stream and std::sort) is built on the host either way, and images
+ * do not depend on this switch (the guard test against the reference's boxes decides every hit).
+ * rt_last_build_ms(): device time of the last such build.  rt_read_search_structure(): the entries and
+ * leaf references the context's kernels walk (layout of rt_scene_get_search_structure), read back from
+ * the device; sizes first with NULL arrays. */
+int rt_set_device_build(rt_context* ctx, int on);
+int rt_last_build_ms(rt_context* ctx, float* ms);
+int rt_read_search_structure(rt_context* ctx, int* n_entries, uint32_t* entries8, int* n_refs, uint32_t* refs);
+
 /* Copies the flattened scene, camera and background to the device (replaces what
  * `Raytracer`'s constructor captures from Scene&, Raytracer.h:27-31). */
 int rt_upload_scene(rt_context* ctx, rt_scene* s);

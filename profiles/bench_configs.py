@@ -99,6 +99,45 @@ def c5s(n_tris, w=1920, h=1080, spp=16, check=True):
         lambda s: scenes.instanced_mesh_scene(s, mesh, copies, tex), w, h, spp, [h // 2] if check else [], oracle_spp=1)
 
 
+def build_compare(n_tris, w=1920, h=1080, spp=16):
+    """Host (surface-area heuristic, threaded) against device (linear BVH) build of the search structure
+    for the instanced-vase scene: seconds until the scene is resident, and the render time each gives."""
+    mesh = scenes.load_gltf_mesh(G)
+    per = mesh["indices"].shape[0]
+    copies = max(1, n_tris // per)
+    tex = {"diffuse": scenes.noise_texture(1024, 1), "roughness": scenes.noise_texture(1024, 2), "normal": None}
+    out = {"case": f"search-structure build, {copies * per} triangles", "size": [w, h], "spp": spp}
+    images = {}
+    for mode in ("host", "device"):
+        t0 = time.perf_counter()
+        a = rt.Scene()
+        scenes.instanced_mesh_scene(a, mesh, copies, tex)
+        t_scene = time.perf_counter() - t0          # triangle list + reference-order BVH (host either way)
+        ctx = rt.Context(0)
+        ctx.set_device_build(mode == "device")
+        t0 = time.perf_counter()
+        ctx.upload_scene(a)                         # flatten (+ host build) + upload (+ device build)
+        t_upload = time.perf_counter() - t0
+        ctx.set_target(w, h)
+        ctx.render(0, 2, 50)
+        ctx.sync()
+        ctx.clear()
+        ctx.render(0, spp, 50)
+        ctx.sync()
+        ms = ctx.last_render_ms()
+        images[mode] = ctx.read_accum()
+        cnt = ctx.count(0, 2, 50)
+        out[mode] = {"scene_and_reference_bvh_s": round(t_scene, 2), "flatten_build_upload_s": round(t_upload, 2),
+                     "device_build_ms": round(ctx.last_build_ms(), 2), "kernel_ms": round(ms, 2),
+                     "node_tests_per_ray": round(cnt["node_tests"] / cnt["rays"], 1),
+                     "prim_tests_per_ray": round(cnt["tri_tests"] / cnt["rays"], 2),
+                     "entries": int(ctx.read_search_structure()[0].shape[0])}
+        ctx.close()
+        print(f"[build {mode}] {out[mode]}", file=sys.stderr, flush=True)
+    out["images_identical"] = bool(np.array_equal(images["host"].view(np.uint32), images["device"].view(np.uint32)))
+    print(json.dumps(out), flush=True)
+
+
 def heartbeat():
     import threading
 
@@ -120,6 +159,8 @@ if __name__ == "__main__":
             c3()
         elif a == "c4":
             c4()
+        elif a.startswith("build"):
+            build_compare(int(float(a.split(":")[1])) if ":" in a else 1_000_000)
         elif a.startswith("c5s"):
             parts = a.split(":")   # c5s[:triangles[:nocheck]] -- nocheck skips the oracle rows (profiling runs)
             c5s(int(float(parts[1])) if len(parts) > 1 else 1_000_000, check=not (len(parts) > 2 and parts[2] == "nocheck"))

@@ -84,6 +84,9 @@ SYMBOLS = {
     "rt_destroy": (None, [_VP]),
     "rt_set_stream": (_I, [_VP, _VP]),
     "rt_set_reference_traversal": (_I, [_VP, _I]),
+    "rt_set_device_build": (_I, [_VP, _I]),
+    "rt_last_build_ms": (_I, [_VP, C.POINTER(C.c_float)]),
+    "rt_read_search_structure": (_I, [_VP, C.POINTER(_I), _VP, C.POINTER(_I), _VP]),
     "rt_upload_scene": (_I, [_VP, _VP]),
     "rt_set_target": (_I, [_VP, _I, _I, _I, _I]),
     "rt_set_target_external": (_I, [_VP, _I, _I, _I, _I, _VP]),
@@ -339,6 +342,23 @@ class Context:
 
     def set_reference_traversal(self, on):
         _check(lib.rt_set_reference_traversal(self.h, 1 if on else 0))
+
+    def set_device_build(self, on):
+        _check(lib.rt_set_device_build(self.h, 1 if on else 0))
+
+    def last_build_ms(self):
+        ms = C.c_float()
+        _check(lib.rt_last_build_ms(self.h, C.byref(ms)))
+        return ms.value
+
+    def read_search_structure(self):
+        """(entries [n, 8] uint32, refs [m] uint32) as the context's kernels walk them, from the device."""
+        ne, nr = C.c_int(0), C.c_int(0)
+        _check(lib.rt_read_search_structure(self.h, C.byref(ne), None, C.byref(nr), None))
+        entries = np.zeros((ne.value, 8), np.uint32)
+        refs = np.zeros(nr.value, np.uint32)
+        _check(lib.rt_read_search_structure(self.h, None, _p(entries), None, _p(refs)))
+        return entries, refs
 
     def upload_scene(self, scene):
         _check(lib.rt_upload_scene(self.h, scene.h))

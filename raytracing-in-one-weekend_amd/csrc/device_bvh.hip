@@ -1,0 +1,362 @@
+// Device-side build of the search structure (the tree the kernels walk first; fast_bvh.cpp builds the
+// same thing on the host with a surface-area heuristic).  No counterpart in the reference, whose
+// BVHNode constructor (R/src/AccelerationStructures/Bvh.h:18-78) is sequential by its use of one
+// random stream and std::sort; that tree is still built on the host, in the reference's order.  What
+// is built here only has to be CONSERVATIVE: every primitive's padded box inside the boxes of all the
+// entries above it.  Which primitive a ray returns is decided by the exact primitive tests and the
+// guard test against the reference's boxes, so any such tree gives the reference's image.
+//
+// Method: a linear BVH.  Padded primitive boxes -> 63-bit Morton codes of their centres -> radix sort
+// (hipCUB) -> one internal node per adjacent pair by the longest-common-prefix construction (Karras,
+// "Maximizing parallelism in the construction of BVHs, octrees and k-d trees", 2012) -> boxes and
+// subtree sizes bottom-up -> entries written in walk order with their skip links.  Internal nodes
+// whose two children are both primitives become one entry with a run of two.
+//
+// Hand-offs between threads of one launch are avoided on purpose: the bottom-up pass runs as one
+// launch per tree level (a node is computed in the launch after both its children were), so every
+// value a thread reads was written by an EARLIER kernel on the same stream.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <cstdint>
+#include <cstdio>
+#include <vector>
+
+#include "rt_device.h"
+
+namespace rt {
+
+namespace {
+
+constexpr uint32_t kTri = 1u << 30, kLast = 1u << 31, kId = kTri - 1;
+
+struct BuildArgs {
+    int n;                      // primitives in the world
+    const uint32_t* refs;       // their leaf references (kind flag + id), any order
+    const float4* spheres;      // {c.xyz, r}
+    const float4* tris;         // 3 x float4: v0, v1 - v0, v2 - v0
+    float pad_floor;
+    float cmin[3], cinv[3];     // centre bounds: (c - cmin) * cinv in [0, 1]
+    float4* pbox;               // 2 per primitive, input order: {min.xyz, -}, {max.xyz, -}
+    uint64_t* keys;
+    uint32_t* order;            // value array of the sort: position in `refs`
+};
+
+// Same padding rule as the host builder: 2e-4 of the box's largest coordinate + 1e-4, and at least
+// the floor that covers far ray origins, capped at a tenth of the primitive's own size.
+__device__ __forceinline__ void paddedBox(const BuildArgs& a, int i, float mn[3], float mx[3]) {
+    const uint32_t ref = a.refs[i];
+    const uint32_t id = ref & kId;
+    if (ref & kTri) {
+        const float4 v0 = a.tris[3 * (size_t)id], e1 = a.tris[3 * (size_t)id + 1], e2 = a.tris[3 * (size_t)id + 2];
+        const float p0[3] = {v0.x, v0.y, v0.z}, p1[3] = {v0.x + e1.x, v0.y + e1.y, v0.z + e1.z},
+                    p2[3] = {v0.x + e2.x, v0.y + e2.y, v0.z + e2.z};
+        for (int k = 0; k < 3; k++) {
+            mn[k] = fminf(p0[k], fminf(p1[k], p2[k]));
+            mx[k] = fmaxf(p0[k], fmaxf(p1[k], p2[k]));
+        }
+    } else {
+        const float4 s = a.spheres[id];
+        const float c[3] = {s.x, s.y, s.z}, r = fabsf(s.w);
+        for (int k = 0; k < 3; k++) {
+            mn[k] = c[k] - r;
+            mx[k] = c[k] + r;
+        }
+    }
+    float m = 0.0f, size = 0.0f;
+    for (int k = 0; k < 3; k++) {
+        m = fmaxf(m, fmaxf(fabsf(mn[k]), fabsf(mx[k])));
+        size = fmaxf(size, mx[k] - mn[k]);
+    }
+    // (the host pads by max(own, min(floor, size / 10)); the edges are re-derived here from v0 + edge,
+    // which may differ from the stored vertex in the last bit -- 1e3 times less than the padding)
+    const float d = fmaxf(2e-4f * m + 1e-4f, fminf(a.pad_floor, 0.1f * size)) * 1.001f;
+    for (int k = 0; k < 3; k++) {
+        mn[k] -= d;
+        mx[k] += d;
+    }
+}
+
+__device__ __forceinline__ uint64_t spread21(uint32_t v) {  // 21 bits -> every third bit of 63
+    uint64_t x = v & 0x1fffffu;
+    x = (x | x << 32) & 0x1f00000000ffffull;
+    x = (x | x << 16) & 0x1f0000ff0000ffull;
+    x = (x | x << 8) & 0x100f00f00f00f00full;
+    x = (x | x << 4) & 0x10c30c30c30c30c3ull;
+    x = (x | x << 2) & 0x1249249249249249ull;
+    return x;
+}
+
+__global__ void __launch_bounds__(256) primitiveKeys(BuildArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    float mn[3], mx[3];
+    paddedBox(a, i, mn, mx);
+    a.pbox[2 * (size_t)i] = make_float4(mn[0], mn[1], mn[2], 0.f);
+    a.pbox[2 * (size_t)i + 1] = make_float4(mx[0], mx[1], mx[2], 0.f);
+    uint64_t key = 0;
+    for (int k = 0; k < 3; k++) {
+        float t = (0.5f * (mn[k] + mx[k]) - a.cmin[k]) * a.cinv[k];
+        t = fminf(fmaxf(t, 0.0f), 1.0f);
+        key |= spread21((uint32_t)(t * 2097151.0f)) << k;
+    }
+    a.keys[i] = key;
+    a.order[i] = (uint32_t)i;
+}
+
+struct Tree {
+    int n;
+    const uint64_t* keys;     // sorted
+    const uint32_t* order;    // sorted position -> position in `refs`
+    int* left;                // per internal node: child >= 0 internal node, < 0 leaf ~child
+    int* right;
+    int* parent;              // [0, n-1): internal nodes, [n-1, 2n-1): leaves; -1 for the root
+    int* first;               // first and last leaf (sorted position) below an internal node
+    int* last;
+    float4* nbox;             // 2 per internal node
+    int* count;               // entries the subtree emits
+    int* stamp;               // number of the fitLevel launch that computed the node; 0 = not yet
+    int* pending;             // [0]: internal nodes still without a box
+};
+
+// Length of the common prefix of the keys at sorted positions i and j (ties broken by position),
+// -1 when j is outside the array.
+__device__ __forceinline__ int prefix(const Tree& t, int i, int j) {
+    if (j < 0 || j >= t.n) return -1;
+    const uint64_t a = t.keys[i], b = t.keys[j];
+    if (a == b) return 64 + __clz((unsigned)(i ^ j));
+    return __clzll((long long)(a ^ b));
+}
+
+__global__ void __launch_bounds__(256) hierarchy(Tree t) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= t.n - 1) return;
+    const int d = prefix(t, i, i + 1) - prefix(t, i, i - 1) >= 0 ? 1 : -1;
+    const int dmin = prefix(t, i, i - d);
+    int lmax = 2;
+    while (prefix(t, i, i + lmax * d) > dmin) lmax *= 2;
+    int l = 0;
+    for (int s = lmax / 2; s >= 1; s /= 2)
+        if (prefix(t, i, i + (l + s) * d) > dmin) l += s;
+    const int j = i + l * d;
+    const int dnode = prefix(t, i, j);
+    int s = 0, step = l;
+    do {
+        step = (step + 1) >> 1;
+        if (prefix(t, i, i + (s + step) * d) > dnode) s += step;
+    } while (step > 1);
+    const int gamma = i + s * d + (d < 0 ? -1 : 0);
+    const int lo = i < j ? i : j, hi = i < j ? j : i;
+    const int lc = lo == gamma ? ~gamma : gamma, rc = hi == gamma + 1 ? ~(gamma + 1) : gamma + 1;
+    t.left[i] = lc;
+    t.right[i] = rc;
+    t.first[i] = lo;
+    t.last[i] = hi;
+    t.parent[lc < 0 ? (t.n - 1) + ~lc : lc] = i;
+    t.parent[rc < 0 ? (t.n - 1) + ~rc : rc] = i;
+    t.count[i] = 0;
+    t.stamp[i] = 0;
+    if (i == 0) t.parent[0] = -1;
+}
+
+// One level of the bottom-up pass, launch number `launch` (1, 2, ...): an internal node whose children
+// were both finished by EARLIER launches (stamp below this launch's number) takes the union of their
+// boxes and its subtree's entry count.  A child finished by another thread of this same launch is
+// left for the next one, so nothing is read that a concurrent thread may still be writing.
+__global__ void __launch_bounds__(256) fitLevel(Tree t, const float4* pbox, int launch) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= t.n - 1 || t.stamp[i] != 0) return;
+    const int lc = t.left[i], rc = t.right[i];
+    const int sl = lc < 0 ? -1 : t.stamp[lc], sr = rc < 0 ? -1 : t.stamp[rc];
+    if (sl == 0 || sl >= launch || sr == 0 || sr >= launch) return;
+    const int cl = lc < 0 ? 1 : t.count[lc], cr = rc < 0 ? 1 : t.count[rc];
+    auto boxOf = [&](int c, float4& mn, float4& mx) {
+        if (c < 0) {
+            const size_t p = t.order[~c];
+            mn = pbox[2 * p];
+            mx = pbox[2 * p + 1];
+        } else {
+            mn = t.nbox[2 * (size_t)c];
+            mx = t.nbox[2 * (size_t)c + 1];
+        }
+    };
+    float4 amn, amx, bmn, bmx;
+    boxOf(lc, amn, amx);
+    boxOf(rc, bmn, bmx);
+    t.nbox[2 * (size_t)i] = make_float4(fminf(amn.x, bmn.x), fminf(amn.y, bmn.y), fminf(amn.z, bmn.z), 0.f);
+    t.nbox[2 * (size_t)i + 1] = make_float4(fmaxf(amx.x, bmx.x), fmaxf(amx.y, bmx.y), fmaxf(amx.z, bmx.z), 0.f);
+    // a node over two primitives is ONE entry with a run of two; otherwise itself plus both subtrees
+    t.count[i] = (lc < 0 && rc < 0) ? 1 : 1 + cl + cr;
+    t.stamp[i] = launch;
+    atomicSub(t.pending, 1);
+}
+
+struct EmitArgs {
+    Tree t;
+    const float4* pbox;
+    const uint32_t* refs;
+    float4* entries;    // 2 per entry: {min.x, max.x, min.y, max.y}, {min.z, max.z, skip, first_ref}
+    uint32_t* out_refs; // leaf references in sorted order
+};
+
+// Position of a node in walk order (entry, then left subtree, then right subtree): one for every
+// ancestor, plus the size of the left sibling subtree wherever the path turns right.
+__device__ __forceinline__ int walkIndex(const Tree& t, int slot) {
+    int idx = 0, cur = slot;
+    for (int p = t.parent[cur]; p >= 0; p = t.parent[cur]) {
+        const int rc = t.right[p];
+        const int rslot = rc < 0 ? (t.n - 1) + ~rc : rc;
+        idx += 1;
+        if (rslot == cur) {
+            const int lc = t.left[p];
+            idx += lc < 0 ? 1 : t.count[lc];
+        }
+        cur = p;
+    }
+    return idx;
+}
+
+__device__ __forceinline__ void writeEntry(const EmitArgs& e, int idx, float4 mn, float4 mx, int skip, int firstRef) {
+    e.entries[2 * (size_t)idx] = make_float4(mn.x, mx.x, mn.y, mx.y);
+    e.entries[2 * (size_t)idx + 1] = make_float4(mn.z, mx.z, __int_as_float(skip), __int_as_float(firstRef));
+}
+
+__global__ void __launch_bounds__(256) emitEntries(EmitArgs e) {
+    const Tree& t = e.t;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < t.n - 1) {  // internal node i
+        const bool twig = t.left[i] < 0 && t.right[i] < 0;
+        const int idx = walkIndex(t, i);
+        writeEntry(e, idx, t.nbox[2 * (size_t)i], t.nbox[2 * (size_t)i + 1], idx + t.count[i], twig ? t.first[i] : -1);
+    }
+    if (i < t.n) {      // leaf at sorted position i
+        const size_t p = t.order[i];
+        const int par = t.n > 1 ? t.parent[(t.n - 1) + i] : -1;
+        const bool underTwig = par >= 0 && t.left[par] < 0 && t.right[par] < 0;
+        const bool lastOfRun = !underTwig || i == t.last[par];
+        e.out_refs[i] = e.refs[p] | (lastOfRun ? kLast : 0u);
+        if (!underTwig) {  // an entry of its own with a run of one
+            const int idx = t.n > 1 ? walkIndex(t, (t.n - 1) + i) : 0;
+            writeEntry(e, idx, e.pbox[2 * p], e.pbox[2 * p + 1], idx + 1, i);
+        }
+    }
+}
+
+}  // namespace
+
+// Builds the search structure of `n` primitives on the device.  All buffers are allocated here and
+// handed to the caller (who frees them with hipFree): *entries (2 float4 per entry), *out_refs.
+// Returns the number of entries through *n_entries.  Blocking (it reads two words back).
+hipError_t buildSearchStructureOnDevice(int n, const uint32_t* d_refs, const float4* d_spheres, const float4* d_tris,
+                                        float pad_floor, const float cmin[3], const float cmax[3], hipStream_t stream,
+                                        float4** entries, uint32_t** out_refs, int* n_entries, float* build_ms) {
+    *entries = nullptr;
+    *out_refs = nullptr;
+    *n_entries = 0;
+    if (n <= 0) return hipErrorInvalidValue;
+    hipError_t e = hipSuccess;
+    std::vector<void*> temp;
+    auto alloc = [&](void** p, size_t bytes) {
+        if (e != hipSuccess) return;
+        e = hipMalloc(p, bytes ? bytes : 16);
+        if (e == hipSuccess) temp.push_back(*p);
+    };
+    const size_t N = (size_t)n;
+    float4 *pbox = nullptr, *nbox = nullptr;
+    uint64_t *keysA = nullptr, *keysB = nullptr;
+    uint32_t *ordA = nullptr, *ordB = nullptr;
+    int *left = nullptr, *right = nullptr, *parent = nullptr, *first = nullptr, *last = nullptr, *count = nullptr, *stamp = nullptr, *pending = nullptr;
+    void* sortTemp = nullptr;
+    size_t sortBytes = 0;
+    alloc((void**)&pbox, N * 32);
+    alloc((void**)&nbox, N * 32);
+    alloc((void**)&keysA, N * 8);
+    alloc((void**)&keysB, N * 8);
+    alloc((void**)&ordA, N * 4);
+    alloc((void**)&ordB, N * 4);
+    alloc((void**)&left, N * 4);
+    alloc((void**)&right, N * 4);
+    alloc((void**)&parent, 2 * N * 4);
+    alloc((void**)&first, N * 4);
+    alloc((void**)&last, N * 4);
+    alloc((void**)&count, N * 4);
+    alloc((void**)&stamp, N * 4);
+    alloc((void**)&pending, 256);
+    if (e == hipSuccess) e = hipcub::DeviceRadixSort::SortPairs(nullptr, sortBytes, keysA, keysB, ordA, ordB, n, 0, 63, stream);
+    alloc(&sortTemp, sortBytes);
+    float4* outEntries = nullptr;
+    uint32_t* outRefs = nullptr;
+    if (e == hipSuccess) e = hipMalloc((void**)&outEntries, (2 * N) * 32);
+    if (e == hipSuccess) e = hipMalloc((void**)&outRefs, N * 4);
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (e == hipSuccess) e = hipEventCreate(&ev0);
+    if (e == hipSuccess) e = hipEventCreate(&ev1);
+    if (e == hipSuccess) e = hipEventRecord(ev0, stream);
+    const int blocks = (n + 255) / 256;
+    if (e == hipSuccess) {
+        BuildArgs a{};
+        a.n = n;
+        a.refs = d_refs;
+        a.spheres = d_spheres;
+        a.tris = d_tris;
+        a.pad_floor = pad_floor;
+        for (int k = 0; k < 3; k++) {
+            a.cmin[k] = cmin[k];
+            const float ext = cmax[k] - cmin[k];
+            a.cinv[k] = ext > 0.0f ? 1.0f / ext : 0.0f;
+        }
+        a.pbox = pbox;
+        a.keys = keysA;
+        a.order = ordA;
+        primitiveKeys<<<blocks, 256, 0, stream>>>(a);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipcub::DeviceRadixSort::SortPairs(sortTemp, sortBytes, keysA, keysB, ordA, ordB, n, 0, 63, stream);
+    Tree t{n, keysB, ordB, left, right, parent, first, last, nbox, count, stamp, pending};
+    int total = 1;
+    if (e == hipSuccess && n > 1) {
+        int todo = n - 1;
+        e = hipMemcpyAsync(pending, &todo, sizeof todo, hipMemcpyHostToDevice, stream);
+        if (e == hipSuccess) {
+            hierarchy<<<blocks, 256, 0, stream>>>(t);
+            e = hipGetLastError();
+        }
+        // one launch per level; how many nodes are left is read back every eight levels (a Morton tree
+        // is at most 63 + 32 levels deep: 63 key bits, then ties split by position)
+        for (int launch = 1; e == hipSuccess && todo > 0;) {
+            if (launch > 256) {
+                e = hipErrorUnknown;  // cannot happen for a well-formed tree
+                break;
+            }
+            for (int k = 0; k < 8 && e == hipSuccess; k++, launch++) {
+                fitLevel<<<blocks, 256, 0, stream>>>(t, pbox, launch);
+                e = hipGetLastError();
+            }
+            if (e == hipSuccess) e = hipMemcpyAsync(&todo, pending, sizeof todo, hipMemcpyDeviceToHost, stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(&total, count, sizeof total, hipMemcpyDeviceToHost, stream);  // count of the root
+    }
+    if (e == hipSuccess) {
+        EmitArgs ea{t, pbox, d_refs, outEntries, outRefs};
+        emitEntries<<<blocks, 256, 0, stream>>>(ea);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipEventRecord(ev1, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (e == hipSuccess && build_ms) e = hipEventElapsedTime(build_ms, ev0, ev1);
+    if (ev0) (void)hipEventDestroy(ev0);
+    if (ev1) (void)hipEventDestroy(ev1);
+    for (void* p : temp) (void)hipFree(p);
+    if (e != hipSuccess) {
+        if (outEntries) (void)hipFree(outEntries);
+        if (outRefs) (void)hipFree(outRefs);
+        return e;
+    }
+    *entries = outEntries;
+    *out_refs = outRefs;
+    *n_entries = total;
+    return hipSuccess;
+}
+
+}  // namespace rt

@@ -397,8 +397,15 @@ void Scene::buildFastStructure() {
     // structure (fastTestUsable() in the kernels).  The hit-distance arithmetic of the primitives
     // themselves (worst: the sphere discriminant near grazing incidence, whose error grows with the
     // square of the distance to the sphere) is covered by margin, not by a bound.
+    const bool deferred = f.defer_search_build;  // the device builds the structure: only its inputs are prepared
     std::vector<PrimBox> prims;
-    prims.reserve(spheres.size() + triangles.size());
+    if (!deferred) prims.reserve(spheres.size() + triangles.size());
+    f.world_refs.clear();
+    f.world_refs.reserve(spheres.size() + triangles.size());
+    for (int k = 0; k < 3; k++) {
+        f.centroid_min[k] = std::numeric_limits<float>::infinity();
+        f.centroid_max[k] = -std::numeric_limits<float>::infinity();
+    }
     float extent = 0.0f;
     for (size_t i = 0; i < spheres.size(); i++)
         if (f.sphere_ord[i] >= 0)
@@ -408,9 +415,13 @@ void Scene::buildFastStructure() {
             for (int k = 0; k < 9; k++) extent = std::max(extent, std::fabs(triangles[i].pos[k]));
     const float originFloor = extent * (1.01f / 2097152.0f);
     float minPad = std::numeric_limits<float>::infinity();
-    auto pad = [&minPad, originFloor](PrimBox& b) {
+    auto pad = [&minPad, originFloor, &f](PrimBox& b) {
         float m = 0.0f, size = 0.0f;
+        f.world_refs.push_back(b.ref);
         for (int k = 0; k < 3; k++) {
+            const float c = 0.5f * (b.mn[k] + b.mx[k]);
+            f.centroid_min[k] = std::min(f.centroid_min[k], c);
+            f.centroid_max[k] = std::max(f.centroid_max[k], c);
             m = std::max(m, std::max(std::fabs(b.mn[k]), std::fabs(b.mx[k])));
             size = std::max(size, b.mx[k] - b.mn[k]);
         }
@@ -431,7 +442,7 @@ void Scene::buildFastStructure() {
         }
         b.ref = (uint32_t)i;
         pad(b);
-        prims.push_back(b);
+        if (!deferred) prims.push_back(b);
     }
     for (size_t i = 0; i < triangles.size(); i++) {
         if (f.tri_ord[i] < 0) continue;
@@ -443,9 +454,11 @@ void Scene::buildFastStructure() {
         }
         b.ref = (uint32_t)i | kRefTriangle;
         pad(b);
-        prims.push_back(b);
+        if (!deferred) prims.push_back(b);
     }
     f.fast_min_pad = minPad;
+    f.pad_floor = originFloor;
+    if (deferred && !f.world_refs.empty()) return;
     if (prims.empty()) {
         // nothing to search: one entry with an inverted box and no leaf run (whatever its test
         // says, the walk ends without a hit)

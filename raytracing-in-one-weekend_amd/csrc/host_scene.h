@@ -79,6 +79,14 @@ struct FlatScene {
     // subtraction), so rays that start further than fast_min_pad * 2^21 from the coordinate origin
     // are not vouched for by the padding and walk the reference-order array instead.
     float fast_min_pad = 0.0f;
+    // Inputs of a device-side build of the search structure (csrc/device_bvh.hip): the primitives that
+    // are in the world (leaf references without the last-of-run bit), the floor of the box padding,
+    // and the bounds of the padded boxes' centres.  With defer_search_build set, flatten() prepares
+    // these (and the guard tables) and leaves fast_nodes / fast_refs empty.
+    bool defer_search_build = false;
+    std::vector<uint32_t> world_refs;
+    float pad_floor = 0.0f;
+    float centroid_min[3] = {0, 0, 0}, centroid_max[3] = {0, 0, 0};
     std::vector<int32_t> sphere_ord;    // sphere id   -> position in prim_refs (reference visit order)
     std::vector<int32_t> tri_ord;       // triangle id -> position in prim_refs
     std::vector<int32_t> prim_guard;    // position in prim_refs -> innermost box-tested entry of `nodes` above it, or -1

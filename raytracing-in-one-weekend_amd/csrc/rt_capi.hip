@@ -25,6 +25,9 @@ hipError_t launchTrace(const DevScene& sc, int n, const float* rays, int* kind, 
 hipError_t launchScatter(const DevScene& sc, int n, const int* mat, const float* rayIn, const float* p, const float* nrm,
                          const int* front, const float* uv, const unsigned int* key4, float* atten, float* rayOut,
                          int* alive, unsigned int* counterOut, hipStream_t stream);
+hipError_t buildSearchStructureOnDevice(int n, const uint32_t* d_refs, const float4* d_spheres, const float4* d_tris,
+                                        float pad_floor, const float cmin[3], const float cmax[3], hipStream_t stream,
+                                        float4** entries, uint32_t** out_refs, int* n_entries, float* build_ms);
 hipError_t launchReflectance(int n, const float* cosine, const float* refIdx, float* out, hipStream_t stream);
 hipError_t launchResolve(const float4* payloads, size_t stride4, int width, int height, int tiles_per_row_local,
                          int world, int only_rank, int mode, int spp, float4* out32, uint32_t* out8, hipStream_t stream);
@@ -62,6 +65,8 @@ struct rt_context {
     unsigned long long sched_stats[14] = {0};  // from the last rt_count(): {executions, lanes} per operation
     float4* colors = nullptr;  // per-sample radiance of the split mode (grown on demand)
     size_t colors_cap = 0;     // in float4
+    bool device_build = false;  // rt_upload_scene() builds the search structure on the device
+    float build_ms = 0.0f;      // device time of the last such build
     void* resolved = nullptr;  // row-major image the read-out calls resolve into (grown on demand, kept)
     size_t resolved_cap = 0;   // in bytes
 };
@@ -564,6 +569,31 @@ int rt_set_stream(rt_context* ctx, void* hip_stream) {
     return RT_OK;
 }
 
+int rt_set_device_build(rt_context* ctx, int on) {
+    if (!ctx) return fail(RT_ERR_INVALID, "null context");
+    ctx->device_build = on != 0;
+    return RT_OK;
+}
+
+int rt_last_build_ms(rt_context* ctx, float* ms) {
+    if (!ctx || !ms) return fail(RT_ERR_INVALID, "bad arguments");
+    *ms = ctx->build_ms;
+    return RT_OK;
+}
+
+int rt_read_search_structure(rt_context* ctx, int* n_entries, uint32_t* entries8, int* n_refs, uint32_t* refs) {
+    if (!ctx || !ctx->scene_loaded) return fail(RT_ERR_STATE, "rt_upload_scene() has not been called");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const rt::DevScene& d = ctx->dsc;
+    const int nE = d.fast_oct_stride > 0 ? d.fast_oct_stride : d.n_fast_nodes;  // the first of eight copies, if so
+    if (n_entries) *n_entries = nE;
+    if (n_refs) *n_refs = d.n_fast_refs;
+    if (entries8) HIP_TRY(hipMemcpyAsync(entries8, d.fast_nodes, (size_t)nE * 32, hipMemcpyDeviceToHost, ctx->stream));
+    if (refs) HIP_TRY(hipMemcpyAsync(refs, d.fast_refs, (size_t)d.n_fast_refs * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
 int rt_set_reference_traversal(rt_context* ctx, int on) {
     if (!ctx) return fail(RT_ERR_INVALID, "null context");
     ctx->force_ref = on ? 1 : 0;
@@ -576,7 +606,14 @@ int rt_upload_scene(rt_context* ctx, rt_scene* s) {
     HIP_TRY(hipSetDevice(ctx->device));
     rt::Scene& sc = s->sc;
     if (sc.groupsOpen()) return fail(RT_ERR_STATE, "a group is still open (rt_scene_end_group() missing)");
+    // With a device-side build the host prepares the reference-order arrays, the guard tables and the
+    // builder's inputs only; a scene flattened earlier for a device build gets its host-built structure
+    // now if this context wants one.
+    sc.flat.defer_search_build = ctx->device_build;
     sc.flatten();
+    if (!ctx->device_build && sc.flat.fast_nodes.empty()) sc.buildFastStructure();
+    sc.flat.defer_search_build = false;
+    const bool deviceBuild = ctx->device_build && !sc.flat.world_refs.empty();
     for (const auto& m : sc.materials)
         if (m.kind == RT_MAT_PBR && (m.tex_d < 0 || m.tex_d >= (int)sc.textures.size()))
             return fail(RT_ERR_INVALID, "PBR material without a diffuse texture");
@@ -653,14 +690,16 @@ int rt_upload_scene(rt_context* ctx, rt_scene* s) {
         probe.n_tris = (int)sc.triangles.size();
         probe.n_mats = (int)sc.materials.size();
         const bool fitsLds = rt::ldsSceneBytes(probe, false) <= kMaxLdsScene && envInt("RT_LDS", -1) != 0;
-        octants = !fitsLds && sc.flat.fast_oct_stride > 0 && envInt("RT_OCTANTS", 1) != 0;
+        octants = !deviceBuild && !fitsLds && sc.flat.fast_oct_stride > 0 && envInt("RT_OCTANTS", 1) != 0;
     }
     const std::vector<uint32_t>& fastSrc = octants ? sc.flat.fast_oct : sc.flat.fast_nodes;
     std::vector<float4> fastNodes(fastSrc.size() / 4);
     std::memcpy(fastNodes.data(), fastSrc.data(), fastSrc.size() * 4);
-    if ((rc = devUpload(ctx, fastNodes, &d.fast_nodes))) return rc;
+    if (!deviceBuild) {
+        if ((rc = devUpload(ctx, fastNodes, &d.fast_nodes))) return rc;
+        if ((rc = devUpload(ctx, sc.flat.fast_refs, &d.fast_refs))) return rc;
+    }
     d.fast_oct_stride = octants ? sc.flat.fast_oct_stride : 0;
-    if ((rc = devUpload(ctx, sc.flat.fast_refs, &d.fast_refs))) return rc;
     if ((rc = devUpload(ctx, sc.flat.sphere_ord, &d.sphere_ord))) return rc;
     if ((rc = devUpload(ctx, sc.flat.tri_ord, &d.tri_ord))) return rc;
     if ((rc = devUpload(ctx, sc.flat.prim_guard, &d.prim_guard))) return rc;
@@ -678,6 +717,23 @@ int rt_upload_scene(rt_context* ctx, rt_scene* s) {
     d.n_prim_refs = (int)sc.flat.prim_refs.size();
     d.n_fast_nodes = (int)(fastSrc.size() / 8);
     d.n_fast_refs = (int)sc.flat.fast_refs.size();
+    if (deviceBuild) {
+        // the search structure is built where the primitives already are (csrc/device_bvh.hip)
+        const uint32_t* dWorld = nullptr;
+        if ((rc = devUpload(ctx, sc.flat.world_refs, &dWorld))) return rc;
+        float4* entries = nullptr;
+        uint32_t* refs = nullptr;
+        int nEntries = 0;
+        HIP_TRY(rt::buildSearchStructureOnDevice((int)sc.flat.world_refs.size(), dWorld, d.spheres, d.tri_isect,
+                                                 sc.flat.pad_floor, sc.flat.centroid_min, sc.flat.centroid_max, ctx->stream,
+                                                 &entries, &refs, &nEntries, &ctx->build_ms));
+        ctx->scene_allocs.push_back(entries);
+        ctx->scene_allocs.push_back(refs);
+        d.fast_nodes = entries;
+        d.fast_refs = refs;
+        d.n_fast_nodes = nEntries;
+        d.n_fast_refs = (int)sc.flat.world_refs.size();
+    }
     d.force_ref = (ctx->force_ref || hugeCoords) ? 1 : 0;
     d.origin_limit = sc.flat.fast_min_pad * 2097152.0f;  // 2^21, see buildFastStructure()
     ctx->huge_coords = hugeCoords;

@@ -26,9 +26,11 @@ def prim_bounds(flat, ref):
     return c - r, c + r
 
 
-def check_search_structure(scene):
+def check_search_structure(scene, structure=None):
+    """`structure`: (entries, refs) to check instead of the scene's host-built one (e.g. the
+    device-built structure read back from a context)."""
     flat = scene.get_flat()
-    entries, refs = scene.search_structure()
+    entries, refs = structure if structure is not None else scene.search_structure()
     n = len(entries)
     assert n >= 1
     box = entries[:, :6].view(np.float32)
