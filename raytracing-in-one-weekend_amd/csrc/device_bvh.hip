@@ -10,7 +10,13 @@
 // (hipCUB) -> one internal node per adjacent pair by the longest-common-prefix construction (Karras,
 // "Maximizing parallelism in the construction of BVHs, octrees and k-d trees", 2012) -> boxes and
 // subtree sizes bottom-up -> entries written in walk order with their skip links.  Internal nodes
-// whose two children are both primitives become one entry with a run of two.
+// whose two children are both primitives become one entry with a run of two.  As with the host builder,
+// scenes too large for LDS with at most 2 M entries get the entries eight times over, each copy with
+// every node's children ordered near-to-far for one sign pattern of the ray direction (1 M triangles:
+// 75 -> 60 box tests per ray).  The host builder's other refinement -- leaving out inner nodes whose box
+// has more than half the area of the node above -- was tried here with the parent as the yardstick and
+// dropped: a Morton tree has long chains of nearly equal boxes, which that rule flattens into scans of
+// hundreds of siblings (462 box tests per ray).
 //
 // Hand-offs between threads of one launch are avoided on purpose: the bottom-up pass runs as one
 // launch per tree level (a node is computed in the launch after both its children were), so every
@@ -20,6 +26,8 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
+#include <functional>
 #include <vector>
 
 #include "rt_device.h"
@@ -116,6 +124,7 @@ struct Tree {
     float4* nbox;             // 2 per internal node
     int* count;               // entries the subtree emits
     int* stamp;               // number of the fitLevel launch that computed the node; 0 = not yet
+    uint8_t* rfirst;          // bit k: for direction-sign pattern k the right child is visited first
     int* pending;             // [0]: internal nodes still without a box
 };
 
@@ -156,6 +165,7 @@ __global__ void __launch_bounds__(256) hierarchy(Tree t) {
     t.parent[rc < 0 ? (t.n - 1) + ~rc : rc] = i;
     t.count[i] = 0;
     t.stamp[i] = 0;
+    t.rfirst[i] = 0;
     if (i == 0) t.parent[0] = -1;
 }
 
@@ -183,8 +193,18 @@ __global__ void __launch_bounds__(256) fitLevel(Tree t, const float4* pbox, int 
     float4 amn, amx, bmn, bmx;
     boxOf(lc, amn, amx);
     boxOf(rc, bmn, bmx);
-    t.nbox[2 * (size_t)i] = make_float4(fminf(amn.x, bmn.x), fminf(amn.y, bmn.y), fminf(amn.z, bmn.z), 0.f);
-    t.nbox[2 * (size_t)i + 1] = make_float4(fmaxf(amx.x, bmx.x), fmaxf(amx.y, bmx.y), fmaxf(amx.z, bmx.z), 0.f);
+    const float4 mn = make_float4(fminf(amn.x, bmn.x), fminf(amn.y, bmn.y), fminf(amn.z, bmn.z), 0.f);
+    const float4 mx = make_float4(fmaxf(amx.x, bmx.x), fmaxf(amx.y, bmx.y), fmaxf(amx.z, bmx.z), 0.f);
+    t.nbox[2 * (size_t)i] = mn;
+    t.nbox[2 * (size_t)i + 1] = mx;
+    // for every sign pattern of the ray direction: is the right child's box entered first?
+    unsigned mask = 0;
+    for (int k = 0; k < 8; k++) {
+        const float al = ((k & 1) ? -amx.x : amn.x) + ((k & 2) ? -amx.y : amn.y) + ((k & 4) ? -amx.z : amn.z);
+        const float ar = ((k & 1) ? -bmx.x : bmn.x) + ((k & 2) ? -bmx.y : bmn.y) + ((k & 4) ? -bmx.z : bmn.z);
+        if (ar < al) mask |= 1u << k;
+    }
+    t.rfirst[i] = (uint8_t)mask;
     // a node over two primitives is ONE entry with a run of two; otherwise itself plus both subtrees
     t.count[i] = (lc < 0 && rc < 0) ? 1 : 1 + cl + cr;
     t.stamp[i] = launch;
@@ -197,37 +217,54 @@ struct EmitArgs {
     const uint32_t* refs;
     float4* entries;    // 2 per entry: {min.x, max.x, min.y, max.y}, {min.z, max.z, skip, first_ref}
     uint32_t* out_refs; // leaf references in sorted order
+    int copies;         // 1, or 8 direction-ordered copies of `stride` entries each
+    int n_entries;      // entries of one copy
+    int stride;         // n_entries + 1 when copies == 8 (one closing entry per copy)
 };
 
-// Position of a node in walk order (entry, then left subtree, then right subtree): one for every
-// ancestor, plus the size of the left sibling subtree wherever the path turns right.
-__device__ __forceinline__ int walkIndex(const Tree& t, int slot) {
-    int idx = 0, cur = slot;
+// Entries a child contributes to its parent's subtree.
+__device__ __forceinline__ int emitted(const Tree& t, int child) { return child < 0 ? 1 : t.count[child]; }
+
+// Position of a node in walk order for each child order in use (entry, first child's subtree, second
+// child's subtree): one for every ancestor, plus the size of the sibling's subtree wherever the node
+// lies under the child that is visited second.
+__device__ __forceinline__ void walkIndex(const Tree& t, int slot, int copies, int idx[8]) {
+    for (int k = 0; k < 8; k++) idx[k] = 0;
+    int cur = slot;
     for (int p = t.parent[cur]; p >= 0; p = t.parent[cur]) {
-        const int rc = t.right[p];
+        const int lc = t.left[p], rc = t.right[p];
         const int rslot = rc < 0 ? (t.n - 1) + ~rc : rc;
-        idx += 1;
-        if (rslot == cur) {
-            const int lc = t.left[p];
-            idx += lc < 0 ? 1 : t.count[lc];
+        const bool isRight = rslot == cur;
+        const int sibling = emitted(t, isRight ? lc : rc);
+        const unsigned mask = copies == 8 ? t.rfirst[p] : 0u;
+        for (int k = 0; k < copies; k++) {
+            const bool rightFirst = (mask >> k) & 1u;
+            idx[k] += 1 + ((isRight != rightFirst) ? sibling : 0);
         }
         cur = p;
     }
-    return idx;
 }
 
-__device__ __forceinline__ void writeEntry(const EmitArgs& e, int idx, float4 mn, float4 mx, int skip, int firstRef) {
-    e.entries[2 * (size_t)idx] = make_float4(mn.x, mx.x, mn.y, mx.y);
-    e.entries[2 * (size_t)idx + 1] = make_float4(mn.z, mx.z, __int_as_float(skip), __int_as_float(firstRef));
+__device__ __forceinline__ void writeEntry(const EmitArgs& e, const int idx[8], float4 mn, float4 mx, int count, int firstRef) {
+    const int total = e.copies * e.stride;
+    for (int k = 0; k < e.copies; k++) {
+        const int base = k * e.stride;
+        int skip = idx[k] + count;
+        if (e.copies == 8) skip = skip >= e.n_entries ? total : base + skip;  // past the end = the walk is over
+        const size_t at = (size_t)(base + idx[k]);
+        e.entries[2 * at] = make_float4(mn.x, mx.x, mn.y, mx.y);
+        e.entries[2 * at + 1] = make_float4(mn.z, mx.z, __int_as_float(skip), __int_as_float(firstRef));
+    }
 }
 
 __global__ void __launch_bounds__(256) emitEntries(EmitArgs e) {
     const Tree& t = e.t;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int idx[8];
     if (i < t.n - 1) {  // internal node i
         const bool twig = t.left[i] < 0 && t.right[i] < 0;
-        const int idx = walkIndex(t, i);
-        writeEntry(e, idx, t.nbox[2 * (size_t)i], t.nbox[2 * (size_t)i + 1], idx + t.count[i], twig ? t.first[i] : -1);
+        walkIndex(t, i, e.copies, idx);
+        writeEntry(e, idx, t.nbox[2 * (size_t)i], t.nbox[2 * (size_t)i + 1], t.count[i], twig ? t.first[i] : -1);
     }
     if (i < t.n) {      // leaf at sorted position i
         const size_t p = t.order[i];
@@ -236,9 +273,20 @@ __global__ void __launch_bounds__(256) emitEntries(EmitArgs e) {
         const bool lastOfRun = !underTwig || i == t.last[par];
         e.out_refs[i] = e.refs[p] | (lastOfRun ? kLast : 0u);
         if (!underTwig) {  // an entry of its own with a run of one
-            const int idx = t.n > 1 ? walkIndex(t, (t.n - 1) + i) : 0;
-            writeEntry(e, idx, e.pbox[2 * p], e.pbox[2 * p + 1], idx + 1, i);
+            if (t.n > 1)
+                walkIndex(t, (t.n - 1) + i, e.copies, idx);
+            else
+                for (int k = 0; k < 8; k++) idx[k] = 0;
+            writeEntry(e, idx, e.pbox[2 * p], e.pbox[2 * p + 1], 1, i);
         }
+    }
+    if (e.copies == 8 && i < 8) {
+        // the entry after a copy's last one: x planes at +infinity, y and z planes at 0 -- the x distances
+        // are both +inf or both -inf, the others finite, so the intervals never meet and the walk ends
+        const size_t at = (size_t)i * e.stride + e.n_entries;
+        const float inf = __builtin_inff();
+        e.entries[2 * at] = make_float4(inf, inf, 0.f, 0.f);
+        e.entries[2 * at + 1] = make_float4(0.f, 0.f, __int_as_float(8 * e.stride), __int_as_float(-1));
     }
 }
 
@@ -247,9 +295,13 @@ __global__ void __launch_bounds__(256) emitEntries(EmitArgs e) {
 // Builds the search structure of `n` primitives on the device.  All buffers are allocated here and
 // handed to the caller (who frees them with hipFree): *entries (2 float4 per entry), *out_refs.
 // Returns the number of entries through *n_entries.  Blocking (it reads two words back).
+// want_copies(entries of one copy) decides whether the eight direction-ordered copies are written; *stride
+// comes back 0 (one copy) or entries + 1.
 hipError_t buildSearchStructureOnDevice(int n, const uint32_t* d_refs, const float4* d_spheres, const float4* d_tris,
                                         float pad_floor, const float cmin[3], const float cmax[3], hipStream_t stream,
-                                        float4** entries, uint32_t** out_refs, int* n_entries, float* build_ms) {
+                                        const std::function<bool(int)>& want_copies, float4** entries, uint32_t** out_refs,
+                                        int* n_entries, int* stride, float* build_ms) {
+    *stride = 0;
     *entries = nullptr;
     *out_refs = nullptr;
     *n_entries = 0;
@@ -266,6 +318,7 @@ hipError_t buildSearchStructureOnDevice(int n, const uint32_t* d_refs, const flo
     uint64_t *keysA = nullptr, *keysB = nullptr;
     uint32_t *ordA = nullptr, *ordB = nullptr;
     int *left = nullptr, *right = nullptr, *parent = nullptr, *first = nullptr, *last = nullptr, *count = nullptr, *stamp = nullptr, *pending = nullptr;
+    uint8_t* rfirst = nullptr;
     void* sortTemp = nullptr;
     size_t sortBytes = 0;
     alloc((void**)&pbox, N * 32);
@@ -281,12 +334,12 @@ hipError_t buildSearchStructureOnDevice(int n, const uint32_t* d_refs, const flo
     alloc((void**)&last, N * 4);
     alloc((void**)&count, N * 4);
     alloc((void**)&stamp, N * 4);
+    alloc((void**)&rfirst, N);
     alloc((void**)&pending, 256);
     if (e == hipSuccess) e = hipcub::DeviceRadixSort::SortPairs(nullptr, sortBytes, keysA, keysB, ordA, ordB, n, 0, 63, stream);
     alloc(&sortTemp, sortBytes);
     float4* outEntries = nullptr;
     uint32_t* outRefs = nullptr;
-    if (e == hipSuccess) e = hipMalloc((void**)&outEntries, (2 * N) * 32);
     if (e == hipSuccess) e = hipMalloc((void**)&outRefs, N * 4);
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (e == hipSuccess) e = hipEventCreate(&ev0);
@@ -312,7 +365,7 @@ hipError_t buildSearchStructureOnDevice(int n, const uint32_t* d_refs, const flo
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipcub::DeviceRadixSort::SortPairs(sortTemp, sortBytes, keysA, keysB, ordA, ordB, n, 0, 63, stream);
-    Tree t{n, keysB, ordB, left, right, parent, first, last, nbox, count, stamp, pending};
+    Tree t{n, keysB, ordB, left, right, parent, first, last, nbox, count, stamp, rfirst, pending};
     int total = 1;
     if (e == hipSuccess && n > 1) {
         int todo = n - 1;
@@ -336,9 +389,19 @@ hipError_t buildSearchStructureOnDevice(int n, const uint32_t* d_refs, const flo
             if (e == hipSuccess) e = hipStreamSynchronize(stream);
         }
         if (e == hipSuccess) e = hipMemcpyAsync(&total, count, sizeof total, hipMemcpyDeviceToHost, stream);  // count of the root
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    }
+    int copies = 1, strideOut = 0;
+    if (e == hipSuccess) {
+        if (n > 1 && want_copies && want_copies(total)) {
+            copies = 8;
+            strideOut = total + 1;
+        }
+        const size_t nOut = copies == 8 ? (size_t)8 * strideOut : (size_t)total;
+        e = hipMalloc((void**)&outEntries, nOut * 32);
     }
     if (e == hipSuccess) {
-        EmitArgs ea{t, pbox, d_refs, outEntries, outRefs};
+        EmitArgs ea{t, pbox, d_refs, outEntries, outRefs, copies, total, copies == 8 ? strideOut : total};
         emitEntries<<<blocks, 256, 0, stream>>>(ea);
         e = hipGetLastError();
     }
@@ -356,6 +419,7 @@ hipError_t buildSearchStructureOnDevice(int n, const uint32_t* d_refs, const flo
     *entries = outEntries;
     *out_refs = outRefs;
     *n_entries = total;
+    *stride = strideOut;
     return hipSuccess;
 }
 

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -27,7 +28,8 @@ hipError_t launchScatter(const DevScene& sc, int n, const int* mat, const float*
                          int* alive, unsigned int* counterOut, hipStream_t stream);
 hipError_t buildSearchStructureOnDevice(int n, const uint32_t* d_refs, const float4* d_spheres, const float4* d_tris,
                                         float pad_floor, const float cmin[3], const float cmax[3], hipStream_t stream,
-                                        float4** entries, uint32_t** out_refs, int* n_entries, float* build_ms);
+                                        const std::function<bool(int)>& want_copies, float4** entries, uint32_t** out_refs,
+                                        int* n_entries, int* stride, float* build_ms);
 hipError_t launchReflectance(int n, const float* cosine, const float* refIdx, float* out, hipStream_t stream);
 hipError_t launchResolve(const float4* payloads, size_t stride4, int width, int height, int tiles_per_row_local,
                          int world, int only_rank, int mode, int spp, float4* out32, uint32_t* out8, hipStream_t stream);
@@ -585,12 +587,18 @@ int rt_read_search_structure(rt_context* ctx, int* n_entries, uint32_t* entries8
     if (!ctx || !ctx->scene_loaded) return fail(RT_ERR_STATE, "rt_upload_scene() has not been called");
     HIP_TRY(hipSetDevice(ctx->device));
     const rt::DevScene& d = ctx->dsc;
-    const int nE = d.fast_oct_stride > 0 ? d.fast_oct_stride : d.n_fast_nodes;  // the first of eight copies, if so
+    // of eight direction-ordered copies the first one, without its closing entry and with the links
+    // that mean "the walk is over" set to the entry count
+    const bool oct = d.fast_oct_stride > 0;
+    const int nE = oct ? d.fast_oct_stride - 1 : d.n_fast_nodes;
     if (n_entries) *n_entries = nE;
     if (n_refs) *n_refs = d.n_fast_refs;
     if (entries8) HIP_TRY(hipMemcpyAsync(entries8, d.fast_nodes, (size_t)nE * 32, hipMemcpyDeviceToHost, ctx->stream));
     if (refs) HIP_TRY(hipMemcpyAsync(refs, d.fast_refs, (size_t)d.n_fast_refs * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (entries8 && oct)
+        for (int e = 0; e < nE; e++)
+            if (entries8[(size_t)e * 8 + 6] > (uint32_t)nE) entries8[(size_t)e * 8 + 6] = (uint32_t)nE;
     return RT_OK;
 }
 
@@ -723,15 +731,28 @@ int rt_upload_scene(rt_context* ctx, rt_scene* s) {
         if ((rc = devUpload(ctx, sc.flat.world_refs, &dWorld))) return rc;
         float4* entries = nullptr;
         uint32_t* refs = nullptr;
-        int nEntries = 0;
+        int nEntries = 0, stride = 0;
+        // eight direction-ordered copies under the host builder's rule: the tables will not fit LDS,
+        // and there are at most 2 M entries
+        auto wantCopies = [&](int nE) {
+            rt::DevScene probe{};
+            probe.n_fast_nodes = nE;
+            probe.n_fast_refs = (int)sc.flat.world_refs.size();
+            probe.n_spheres = (int)sc.spheres.size();
+            probe.n_tris = (int)sc.triangles.size();
+            probe.n_mats = (int)sc.materials.size();
+            const bool fitsLds = rt::ldsSceneBytes(probe, false) <= kMaxLdsScene && envInt("RT_LDS", -1) != 0;
+            return !fitsLds && nE <= (1 << 21) && envInt("RT_OCTANTS", 1) != 0;
+        };
         HIP_TRY(rt::buildSearchStructureOnDevice((int)sc.flat.world_refs.size(), dWorld, d.spheres, d.tri_isect,
                                                  sc.flat.pad_floor, sc.flat.centroid_min, sc.flat.centroid_max, ctx->stream,
-                                                 &entries, &refs, &nEntries, &ctx->build_ms));
+                                                 wantCopies, &entries, &refs, &nEntries, &stride, &ctx->build_ms));
         ctx->scene_allocs.push_back(entries);
         ctx->scene_allocs.push_back(refs);
         d.fast_nodes = entries;
         d.fast_refs = refs;
-        d.n_fast_nodes = nEntries;
+        d.n_fast_nodes = stride > 0 ? 8 * stride : nEntries;
+        d.fast_oct_stride = stride;
         d.n_fast_refs = (int)sc.flat.world_refs.size();
     }
     d.force_ref = (ctx->force_ref || hugeCoords) ? 1 : 0;
