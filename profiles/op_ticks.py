@@ -31,7 +31,7 @@ st = ctx.sched_stats()
 vals = [x for pair in st.values() for x in pair]   # the 14 raw slots
 names = ["box bursts", "primitive runs", "shade: guard test", "shade: surface", "shade: scatter",
          "shade: next ray / end of path", "newpath: finish missed path", "newpath: queue refill",
-         "newpath: camera ray", "reference-order box steps", "votes and the rest"]
+         "newpath: camera ray", "reference-order box steps", "votes and the rest", "shade: set-up of the next ray"]
 ticks = vals[:len(names)]
 waves = vals[13]
 total = sum(ticks)

@@ -778,7 +778,7 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
     if (lane == 0) chunkAhead = fetchChunk();
     unsigned long long schedExec[7] = {0, 0, 0, 0, 0, 0, 0}, schedLanes[7] = {0, 0, 0, 0, 0, 0, 0};
     // TIME: ticks per stretch of the loop (T_* below); tMark = last reading
-    enum { T_BOX, T_PRIM, T_GUARD, T_SURFACE, T_SCATTER, T_SHADE_TAIL, T_FINISH, T_REFILL, T_CAMERA, T_REFBOX, T_REST, T_N };
+    enum { T_BOX, T_PRIM, T_GUARD, T_SURFACE, T_SCATTER, T_SHADE_TAIL, T_FINISH, T_REFILL, T_CAMERA, T_REFBOX, T_REST, T_RAYSETUP, T_N };
     unsigned long long ticks[T_N] = {0}, tMark = 0;
     auto lap = [&](int slot) {  // charges the time since the last reading to `slot`
         if (TIME) {
@@ -993,7 +993,9 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
                             if (COUNT) st.v[C_CUTOFF]++;
                             endPath(V3{0.0f, 0.0f, 0.0f});
                         } else {
+                            lap(T_SHADE_TAIL);
                             startRay();
+                            lap(T_RAYSETUP);
                         }
                     }
                 }
