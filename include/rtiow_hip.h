@@ -309,6 +309,28 @@ int rt_resolve_gathered(rt_context* ctx, const void* device_payloads, int world,
 int rt_resolve_gathered_rgba8(rt_context* ctx, const void* device_payloads, int world, int samples_per_pixel,
                               void* device_rgba8);
 
+/* ------------------------------------------------------------------ several GPUs, one process
+ *
+ * No counterpart in the reference (a single-device application; its render thread is one host thread,
+ * R/src/RaytracingApplication.cpp:244-276): a group drives n devices of one node from ONE host process
+ * and owns the RCCL communicator between them (loaded at run time; RT_ERR_STATE when librccl cannot
+ * be loaded).  The scene is replicated; device i renders the 8x8 tiles with (tx + ty) mod n == i; a read
+ * call all-gathers the n payloads over xGMI (one ncclAllGather per frame), resolves them on device 0
+ * and copies the frame to the host.  The frame has the same bits for every n.  devices = NULL means
+ * devices 0 .. n-1.  Errors of these calls: rt_group_last_error(). */
+typedef struct rt_group rt_group;
+int rt_group_create(int n_devices, const int* devices, rt_group** out);
+void rt_group_destroy(rt_group* g);
+int rt_group_size(const rt_group* g);
+rt_context* rt_group_context(rt_group* g, int i);      /* the context of device i (e.g. for rt_count) */
+int rt_group_upload_scene(rt_group* g, rt_scene* s);
+int rt_group_set_target(rt_group* g, int width, int height);
+int rt_group_clear(rt_group* g);
+int rt_group_render(rt_group* g, int first_sample, int n_samples, int max_depth); /* asynchronous, all devices */
+int rt_group_read_rgba8(rt_group* g, int samples_per_pixel, uint8_t* dst);        /* gather + resolve + copy; blocking */
+int rt_group_read_accum_rgba32f(rt_group* g, float* dst);
+const char* rt_group_last_error(void);
+
 /* Test hook: closest hit of n rays (origin xyz, direction xyz) with tMin = 0.001, as
  * mWorld.Hit(r, 0.001f, infinity, rec) (Raytracer.cpp:10).  prim_kind: -1 miss, 0 sphere,
  * 1 triangle.  Optional outputs may be NULL.  Host pointers; blocking. */

@@ -103,6 +103,17 @@ SYMBOLS = {
     "rt_write_ppm": (_I, [C.c_char_p, _I, _I, _VP]),
     "rt_resolve_gathered": (_I, [_VP, _VP, _I, _VP]),
     "rt_resolve_gathered_rgba8": (_I, [_VP, _VP, _I, _I, _VP]),
+    "rt_group_create": (_I, [_I, _VP, C.POINTER(_VP)]),
+    "rt_group_destroy": (None, [_VP]),
+    "rt_group_size": (_I, [_VP]),
+    "rt_group_context": (_VP, [_VP, _I]),
+    "rt_group_upload_scene": (_I, [_VP, _VP]),
+    "rt_group_set_target": (_I, [_VP, _I, _I]),
+    "rt_group_clear": (_I, [_VP]),
+    "rt_group_render": (_I, [_VP, _I, _I, _I]),
+    "rt_group_read_rgba8": (_I, [_VP, _I, _VP]),
+    "rt_group_read_accum_rgba32f": (_I, [_VP, _VP]),
+    "rt_group_last_error": (C.c_char_p, []),
     "rt_trace": (_I, [_VP, _I] + [_VP] * 7),
     "rt_scatter_test": (_I, [_VP, _I] + [_VP] * 11),
     "rt_reflectance_test": (_I, [_VP, _I, _VP, _VP, _VP]),
@@ -463,6 +474,55 @@ class Context:
     @property
     def stream(self):
         return lib.rt_stream(self.h)
+
+
+class Group:
+    """Several GPUs of one node from one process (rt_group_*): tiles sharded over the devices, one RCCL
+    all-gather per frame, resolve on device 0."""
+
+    def __init__(self, devices):
+        devs = np.ascontiguousarray(devices, dtype=np.int32)
+        h = C.c_void_p()
+        self._check(lib.rt_group_create(devs.size, _p(devs), C.byref(h)))
+        self.h = h
+        self.width = self.height = 0
+
+    @staticmethod
+    def _check(rc):
+        if rc < 0:
+            raise RtError(rc, lib.rt_group_last_error().decode())
+        return rc
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib.rt_group_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def upload_scene(self, scene):
+        self._check(lib.rt_group_upload_scene(self.h, scene.h))
+
+    def set_target(self, width, height):
+        self._check(lib.rt_group_set_target(self.h, width, height))
+        self.width, self.height = width, height
+
+    def clear(self):
+        self._check(lib.rt_group_clear(self.h))
+
+    def render(self, first_sample, n_samples, max_depth=50):
+        self._check(lib.rt_group_render(self.h, first_sample, n_samples, max_depth))
+
+    def read_rgba8(self, samples_per_pixel):
+        out = np.zeros((self.height, self.width, 4), np.uint8)
+        self._check(lib.rt_group_read_rgba8(self.h, samples_per_pixel, _p(out)))
+        return out
+
+    def read_accum(self):
+        out = np.zeros((self.height, self.width, 4), np.float32)
+        self._check(lib.rt_group_read_accum_rgba32f(self.h, _p(out)))
+        return out
 
 
 def write_ppm(path, rgba8):

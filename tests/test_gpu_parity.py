@@ -614,3 +614,31 @@ def test_ingested_tree_renders_like_the_built_one(rt, orc, scenes, gpu_ctx):
     got = render_gpu(gpu_ctx, w, h, 0, spp)
     want, _, _ = o.render(w, h, 0, spp, 50, rng_mode=1, order=1, threads=8)
     assert np.array_equal(bits(got[..., :3]), bits(want[..., :3]))
+
+
+def test_device_group_of_one_gathers_over_rccl(rt, scenes, gpu_ctx):
+    """rt_group_*: the in-library multi-GPU helper with as many devices as this box has (one): contexts,
+    the RCCL communicator (ncclCommInitAll), the all-gather on the render stream and the resolve on
+    device 0 all run; the frame equals the plain single-context render bit for bit."""
+    w, h, spp = 200, 120, 3
+    a = rt.Scene()
+    scenes.cover_scene(a, w, h)
+    gpu_ctx.upload_scene(a)
+    want = render_gpu(gpu_ctx, w, h, 0, spp)
+    want8 = gpu_ctx.read_rgba8(spp)
+    g = rt.Group([0])
+    g.upload_scene(a)
+    g.set_target(w, h)
+    g.render(0, 1, 50)
+    g.render(1, spp - 1, 50)          # progressive: consecutive sample ranges
+    assert np.array_equal(bits(g.read_accum()), bits(want))
+    assert np.array_equal(g.read_rgba8(spp), want8)
+    g.clear()
+    g.render(0, spp, 50)
+    assert np.array_equal(bits(g.read_accum()), bits(want))
+    g.set_target(64, 36)              # re-targeting frees and re-creates the per-device buffers
+    g.render(0, 1, 50)
+    assert g.read_accum()[..., :3].max() > 0
+    g.close()
+    with pytest.raises(rt.RtError):
+        rt.Group([99])                # no such device
