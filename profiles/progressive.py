@@ -38,3 +38,22 @@ for i in range(32):
     ctx.render(32 + i, 1, 50)
 ctx.sync()
 print(f"1-spp passes enqueued back to back: {1e3 * (time.perf_counter() - t0) / 32:.3f} ms per pass", flush=True)
+
+# build-up display: after every 1-spp pass the RGBA8 frame is resolved and copied to the host, as the
+# reference application re-uploads its byte buffer every frame (R/src/RaytracingApplication.cpp:193-194)
+import numpy as np
+frame = np.zeros((H, W, 4), np.uint8)
+t_read = []
+
+
+def show(done):
+    t = time.perf_counter()
+    frame[...] = ctx.read_rgba8(done)
+    t_read.append(time.perf_counter() - t)
+
+
+t0 = time.perf_counter()
+ctx.run(64, 1, 50, on_pass=show)
+dt = time.perf_counter() - t0
+print(f"build-up display, 64 one-sample passes each followed by resolve + RGBA8 read-back: {1e3 * dt:.2f} ms "
+      f"({1e3 * dt / 64:.3f} ms per pass, of which read-back {1e3 * sum(t_read) / 64:.3f} ms)", flush=True)

@@ -1,10 +1,11 @@
 // HIP kernels of the path tracer core for gfx950 (wave64).
 //
-// One lane owns one pixel and walks through that pixel's samples in order, so every
-// pixel's float sum is formed in the same order as the reference's `pixelColor +=`
-// loop (R/src/Core/Raytracer.cpp:84-90) and no atomics touch the image.  One wave owns
-// an 8x8 pixel tile.  Arithmetic follows the reference expression by expression
-// (build with -ffp-contract=off; fp32 divide and sqrt are correctly rounded).
+// The unit of work is one pixel sample (one camera path): persistent waves pull units from a
+// launch-wide queue, every lane runs a small state machine over its current path, and a second kernel
+// adds each pixel's radiances in sample order, which is the order of the reference's `pixelColor +=`
+// loop (R/src/Core/Raytracer.cpp:84-90), so no atomics touch the image.  Arithmetic follows the
+// reference expression by expression (build with -ffp-contract=off; fp32 divide and sqrt are
+// correctly rounded).
 // R/ = /root/reference/Raytracing-In-A-Weekend/.
 #include "rt_device.h"
 
@@ -39,9 +40,11 @@ __device__ __forceinline__ uint32_t hashu(uint32_t x) {
 // (fillCounterLut) so that a draw costs one hash instead of two.
 constexpr int kCounterLut = 256;
 __shared__ uint32_t g_counterLut[kCounterLut];
+__shared__ int g_cancelSeen;  // set by the workgroup's first wave once it has read the caller's cancel flag as up
 
 __device__ __forceinline__ void fillCounterLut() {
     for (int i = threadIdx.x; i < kCounterLut; i += blockDim.x) g_counterLut[i] = hashu(fbits((float)i));
+    if (threadIdx.x == 0) g_cancelSeen = 0;
     __syncthreads();
 }
 
@@ -764,14 +767,24 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
     bool chunkInside = false;
     unsigned int chunkAhead = 0;  // lane 0: the queue index fetched ahead of need
     // Raytracer::Cancel() (R/src/Core/Raytracer.h:59-62; the reference polls its flag once per scanline,
-    // Raytracer.cpp:54,78,148,176): every fetch of a chunk index also reads the caller's flag from pinned
-    // host memory.  Once it is up the wave takes no more chunks (the paths it holds run to their end) and
-    // marks the launch as cut short, which makes accumulateColors() leave the image alone.
+    // Raytracer.cpp:54,78,148,176).  The caller's flag lives in pinned host memory, and a read of it
+    // crosses PCIe, so only the first wave of a workgroup reads it, on every 16th chunk it fetches, and
+    // passes what it saw to the workgroup's other waves through LDS (a read per wave per chunk -- two
+    // million small PCIe reads per frame -- made a 27 ms launch take 180 ms).  A wave that learns of
+    // the flag takes no more chunks (the paths it holds run to their end) and marks the launch as cut
+    // short, which makes accumulateColors() leave the image alone.
+    const bool pollsHost = (threadIdx.x >> 6) == 0;
+    unsigned int fetches = 15;  // the first fetch polls
     auto fetchChunk = [&]() {
         unsigned int c = atomicAdd(a.queue, 1u);
-        if (a.cancel && __hip_atomic_load(a.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) {
-            a.queue[1] = 1u;
-            c = 0xFFFFFFFFu;
+        if (a.cancel) {
+            if (pollsHost && (++fetches & 15u) == 0u &&
+                __hip_atomic_load(a.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM))
+                __hip_atomic_store(&g_cancelSeen, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (__hip_atomic_load(&g_cancelSeen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                a.queue[1] = 1u;
+                c = 0xFFFFFFFFu;
+            }
         }
         return c;
     };
