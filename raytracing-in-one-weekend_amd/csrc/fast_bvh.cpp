@@ -479,13 +479,15 @@ void Scene::buildFastStructure() {
     f.fast_oct_stride = 0;
     auto al = [](size_t x) { return (x + 15) & ~size_t(15); };
     const size_t nE = f.fast_nodes.size() / 8, nS = spheres.size(), nT = triangles.size();
-    const size_t ldsBytes = al(nE * 32) + al(f.fast_refs.size() * 4) + al(nS * 16) + al(nT * 48) + al(nS * 4) + al(nT * 4) +
+    const size_t ldsBytes = al((nE + 1) * 40) + al(f.fast_refs.size() * 4) + al(nS * 16) + al(nT * 48) + al(nS * 4) + al(nT * 4) +
                             al(materials.size() * 32) + al(nS * 4) + al(nT * 4);
     const char* octEnv = std::getenv("RT_FAST_OCTANTS");
     // Measured: 1 M triangles 68.7 -> 62.7 ms (35 instead of 48 box tests per ray); 10 M triangles
     // 145 -> 141 ms for 2 s more build time and 3 GB, so beyond 2 M entries the copies are not made;
     // Cornell + vase unchanged (14 instead of 21 box tests per ray, 296 ms either way).
-    const bool wantOct = octEnv ? std::atoi(octEnv) != 0 : (ldsBytes > 72 * 1024 && nE <= (1u << 21));
+    // (the LDS form of the entries also needs (nE + 1) * 40 and the leaf references to fit 16 bits)
+    const bool fitsLds = ldsBytes <= 72 * 1024 && (nE + 1) * 40 <= 0xFFFF && f.fast_refs.size() < 0xFFFE;
+    const bool wantOct = octEnv ? std::atoi(octEnv) != 0 : (!fitsLds && nE <= (1u << 21));
     if (wantOct && nE * 8 + 8 < 0x7FFFFFFFu) {
         const uint32_t stride = (uint32_t)nE + 1, total = 8 * stride;
         std::vector<uint32_t> copy[8];

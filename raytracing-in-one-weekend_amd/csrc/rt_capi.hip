@@ -92,10 +92,15 @@ int fail(int code, const std::string& msg) {
     g_err = msg;
     return code;
 }
+// A failed runtime call also leaves its code behind as the thread's "last error", which a later,
+// unrelated hipGetLastError() (the check after a kernel launch) would report: it is taken off here.
 #define HIP_TRY(expr)                                                                         \
     do {                                                                                      \
         hipError_t e_ = (expr);                                                               \
-        if (e_ != hipSuccess) return fail(RT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+        if (e_ != hipSuccess) {                                                               \
+            (void)hipGetLastError();                                                          \
+            return fail(RT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));       \
+        }                                                                                     \
     } while (0)
 
 // Largest LDS footprint the staged-scene kernel is allowed to ask for.  Two such workgroups
@@ -441,7 +446,7 @@ int rt_scene_flatten(rt_scene* s, rt_flat_info* info) {
         d.n_spheres = info->n_spheres;
         d.n_tris = info->n_triangles;
         d.n_mats = info->n_materials;
-        info->fits_lds = rt::ldsSceneBytes(d) <= kMaxLdsScene;
+        info->fits_lds = rt::ldsSceneBytes(d) <= kMaxLdsScene && rt::ldsWalkEntriesFit(d);
     }
     return RT_OK;
 }
@@ -697,7 +702,7 @@ int rt_upload_scene(rt_context* ctx, rt_scene* s) {
         probe.n_spheres = (int)sc.spheres.size();
         probe.n_tris = (int)sc.triangles.size();
         probe.n_mats = (int)sc.materials.size();
-        const bool fitsLds = rt::ldsSceneBytes(probe, false) <= kMaxLdsScene && envInt("RT_LDS", -1) != 0;
+        const bool fitsLds = rt::ldsSceneBytes(probe, false) <= kMaxLdsScene && rt::ldsWalkEntriesFit(probe) && envInt("RT_LDS", -1) != 0;
         octants = !deviceBuild && !fitsLds && sc.flat.fast_oct_stride > 0 && envInt("RT_OCTANTS", 1) != 0;
     }
     const std::vector<uint32_t>& fastSrc = octants ? sc.flat.fast_oct : sc.flat.fast_nodes;
@@ -741,7 +746,7 @@ int rt_upload_scene(rt_context* ctx, rt_scene* s) {
             probe.n_spheres = (int)sc.spheres.size();
             probe.n_tris = (int)sc.triangles.size();
             probe.n_mats = (int)sc.materials.size();
-            const bool fitsLds = rt::ldsSceneBytes(probe, false) <= kMaxLdsScene && envInt("RT_LDS", -1) != 0;
+            const bool fitsLds = rt::ldsSceneBytes(probe, false) <= kMaxLdsScene && rt::ldsWalkEntriesFit(probe) && envInt("RT_LDS", -1) != 0;
             return !fitsLds && nE <= (1 << 21) && envInt("RT_OCTANTS", 1) != 0;
         };
         HIP_TRY(rt::buildSearchStructureOnDevice((int)sc.flat.world_refs.size(), dWorld, d.spheres, d.tri_isect,
@@ -776,7 +781,7 @@ int rt_upload_scene(rt_context* ctx, rt_scene* s) {
     else
         ctx->lds_refs = all <= kLdsThreeGroups || (part > kLdsThreeGroups && all <= kMaxLdsScene);
     ctx->lds_need = ctx->lds_refs ? all : part;
-    ctx->use_lds = ctx->lds_need <= kMaxLdsScene && ldsMode != 0;
+    ctx->use_lds = ctx->lds_need <= kMaxLdsScene && rt::ldsWalkEntriesFit(d) && ldsMode != 0;
     ctx->scene_loaded = true;
     return RT_OK;
 }

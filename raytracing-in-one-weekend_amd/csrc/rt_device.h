@@ -72,15 +72,23 @@ constexpr int kTile = 8;  // one wave64 = one 8x8 pixel tile
 // with_reference_arrays = false leaves the reference-order entries, their leaf references and the
 // guard tables in global memory (they are touched once or twice per accepted hit and by the rare
 // re-trace), which lets one more workgroup share a CU's LDS.
+// The search structure is budgeted at 40 bytes per entry plus one closing entry, which is how the
+// persistent kernel lays it out (the plain kernel stages 32 bytes per entry into the same space).
 inline size_t ldsSceneBytes(const DevScene& s, bool with_reference_arrays = true) {
     auto al = [](size_t x) { return (x + 15) & ~size_t(15); };
-    size_t n = al((size_t)s.n_fast_nodes * 32) + al((size_t)s.n_fast_refs * 4) + al((size_t)s.n_spheres * 16) +
+    size_t n = al(((size_t)s.n_fast_nodes + 1) * 40) + al((size_t)s.n_fast_refs * 4) + al((size_t)s.n_spheres * 16) +
                al((size_t)s.n_tris * 48) + al((size_t)s.n_spheres * 4) + al((size_t)s.n_tris * 4) +
                al((size_t)s.n_mats * 32) + al((size_t)s.n_spheres * 4) + al((size_t)s.n_tris * 4);
     if (with_reference_arrays)
         n += al((size_t)s.n_nodes * 32) + al((size_t)s.n_prim_refs * 4) + al((size_t)s.n_prim_refs * 4) +
              al((size_t)s.n_nodes * 4);
     return n;
+}
+
+// The LDS walk entries hold the skip link as a 16-bit byte offset and the leaf run's start as a 16-bit
+// index (0xFFFE and 0xFFFF are reserved): scenes beyond either keep their tables in global memory.
+inline bool ldsWalkEntriesFit(const DevScene& s) {
+    return ((size_t)s.n_fast_nodes + 1) * 40 <= 0xFFFF && s.n_fast_refs < 0xFFFE;
 }
 
 }  // namespace rt

@@ -84,7 +84,10 @@ static int gfail(int code, const std::string& msg) {
 #define GROUP_TRY_HIP(expr)                                                                              \
     do {                                                                                                 \
         hipError_t e_ = (expr);                                                                          \
-        if (e_ != hipSuccess) return gfail(RT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+        if (e_ != hipSuccess) {                                                                          \
+            (void)hipGetLastError();                                                                     \
+            return gfail(RT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                 \
+        }                                                                                                \
     } while (0)
 #define GROUP_TRY_NCCL(expr)                                                                                   \
     do {                                                                                                       \

@@ -108,11 +108,12 @@ struct SceneView {
     const int* tri_ord;
     const int* prim_guard;
     const int* node_outer;
+    const char* wnodes;     // LDS only: the search structure as 40-byte walk entries (see stageScene)
 };
 
 __device__ __forceinline__ SceneView globalView(const DevScene& sc) {
     return SceneView{sc.nodes,      sc.prim_refs, sc.fast_nodes, sc.fast_refs,  sc.spheres,    sc.tri_isect, sc.sphere_mat,
-                     sc.tri_mat,    sc.materials, sc.sphere_ord, sc.tri_ord,    sc.prim_guard, sc.node_outer};
+                     sc.tri_mat,    sc.materials, sc.sphere_ord, sc.tri_ord,    sc.prim_guard, sc.node_outer, nullptr};
 }
 
 constexpr int kNumStats = 14;
@@ -150,6 +151,9 @@ __device__ __forceinline__ bool slabPass(const float4& n0, const float4& n1, con
 }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+struct __attribute__((aligned(4))) f32x2u {  // two floats at a 4-byte aligned address
+    float x, y;
+};
 
 // Box test of the search structure.  It only has to be conservative (never cull a box that
 // holds an accepted hit): which primitive wins is decided by the exact primitive tests and the
@@ -576,8 +580,18 @@ __device__ __forceinline__ V3 rayColor(const DevScene& sc, const SceneView& sv, 
 
 extern __shared__ float4 rt_lds[];
 
+// Walk entry of the search structure in LDS (persistent kernel): ten dwords
+//   {min.x, max.x, min.x,  min.y, max.y, min.y,  min.z, max.z, min.z,  first_ref << 16 | skip}
+// A lane reads each axis as the two dwords that start at 0 (direction component positive) or 4 bytes
+// (negative) into the triple, which hands it {entry plane, exit plane} with no comparison.  `skip` is
+// the byte offset of the entry to go on with after a failed test; first_ref is 0xFFFF for an entry
+// without a leaf run.  The table ends with an entry every ray passes whose first_ref is kWalkEnd:
+// reaching it is how a lane learns that its walk is over.
+constexpr int kWalkEntryBytes = 40;
+constexpr uint32_t kWalkNoLeaf = 0xFFFFu, kWalkEnd = 0xFFFEu;
+
 // Stages the scene tables into LDS and returns views into it (layout = ldsSceneBytes()).
-__device__ __forceinline__ SceneView stageScene(const DevScene& sc, bool withReferenceArrays) {
+__device__ __forceinline__ SceneView stageScene(const DevScene& sc, bool withReferenceArrays, bool walkEntries = false) {
     char* base = reinterpret_cast<char*>(rt_lds);
     int off = 0;
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -597,7 +611,35 @@ __device__ __forceinline__ SceneView stageScene(const DevScene& sc, bool withRef
         return reinterpret_cast<const int*>(take4(reinterpret_cast<const uint32_t*>(src), n));
     };
     SceneView v;
-    v.fnodes = take16(sc.fast_nodes, sc.n_fast_nodes * 2);
+    v.wnodes = nullptr;
+    if (walkEntries) {
+        const int n = sc.n_fast_nodes;
+        uint32_t* dst = reinterpret_cast<uint32_t*>(base + off);
+        off += ((n + 1) * kWalkEntryBytes + 15) & ~15;
+        for (int i = tid; i <= n; i += nt) {
+            uint32_t* e = dst + 10 * i;
+            if (i < n) {
+                const float4 n0 = sc.fast_nodes[2 * i], n1 = sc.fast_nodes[2 * i + 1];
+                const uint32_t skip = fbits(n1.z), first = fbits(n1.w);
+                e[0] = e[2] = fbits(n0.x);
+                e[1] = fbits(n0.y);
+                e[3] = e[5] = fbits(n0.z);
+                e[4] = fbits(n0.w);
+                e[6] = e[8] = fbits(n1.x);
+                e[7] = fbits(n1.y);
+                e[9] = (((int)first < 0 ? kWalkNoLeaf : first) << 16) | ((skip < (uint32_t)n ? skip : (uint32_t)n) * kWalkEntryBytes);
+            } else {
+                const uint32_t lo = fbits(-__builtin_inff()), hi = fbits(__builtin_inff());
+                e[0] = e[2] = e[3] = e[5] = e[6] = e[8] = lo;
+                e[1] = e[4] = e[7] = hi;
+                e[9] = (kWalkEnd << 16) | (uint32_t)(n * kWalkEntryBytes);
+            }
+        }
+        v.wnodes = reinterpret_cast<const char*>(dst);
+        v.fnodes = sc.fast_nodes;
+    } else {
+        v.fnodes = take16(sc.fast_nodes, sc.n_fast_nodes * 2);
+    }
     v.frefs = take4(sc.fast_refs, sc.n_fast_refs);
     v.spheres = take16(sc.spheres, sc.n_spheres);
     v.tris = take16(sc.tri_isect, sc.n_tris * 3);
@@ -732,12 +774,15 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
     fillCounterLut();
     SceneView sv;
     if (LDS) {
-        sv = stageScene(sc, a.knob[2] != 0);
+        sv = stageScene(sc, a.knob[2] != 0, true);
     } else {
         sv = globalView(sc);
     }
     const int lane = threadIdx.x & 63;
+    // `idx` of a lane that walks the search structure: the entry's number, or with the tables in LDS its
+    // byte offset into the walk entries; walkEnd is the value that means "past the last entry"
     const int nNodesRef = sc.n_nodes, nNodesFast = sc.n_fast_nodes;
+    const int walkEnd = LDS ? nNodesFast * kWalkEntryBytes : nNodesFast;
     const float originLimit = sc.origin_limit;
     const int nTiles = a.n_local_tiles;
     const unsigned int nChunks = (unsigned int)nTiles * (unsigned int)a.n_samples;  // 64 units each
@@ -872,7 +917,53 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
             const int total = cBox + cPrim + cShade + cPath + cRef;  // lanes that are not done
             int nBox = cBox, cur = chosen;
             for (;;) {
-                if (cur == OP_BOX) {
+                if (cur == OP_BOX && LDS) {
+                    // Search structure in LDS: conservative fused box test on walk entries.  For the length
+                    // of the burst a lane's membership is the flag `walking` (a lane mask in scalar registers)
+                    // rather than `op`, the entry/exit planes come sorted from the entry's layout, and the end
+                    // of the walk is an entry like any other, so a step is: three address adds, four LDS
+                    // reads, three packed multiply-adds, two three-way and two plain min/max, a compare, and
+                    // the choice of the next entry.
+                    const int keep = boxKeep < nBox ? boxKeep : nBox;  // never spin below what is available
+                    const uint32_t sx = (fbits(invx) >> 29) & 4u, sy = (fbits(invy) >> 29) & 4u, sz = (fbits(invz) >> 29) & 4u;
+                    bool walking = op == OP_BOX;
+                    uint32_t w = 0;
+                    auto boxStep = [&]() {
+                        if (COUNT) {
+                            schedExec[5] += 1;
+                            schedLanes[5] += popc64(__ballot(walking));
+                        }
+                        if (walking) {
+                            const char* e = sv.wnodes + idx;
+                            const f32x2u px = *reinterpret_cast<const f32x2u*>(e + sx);
+                            const f32x2u py = *reinterpret_cast<const f32x2u*>(e + 12 + sy);
+                            const f32x2u pz = *reinterpret_cast<const f32x2u*>(e + 24 + sz);
+                            w = *reinterpret_cast<const uint32_t*>(e + 36);
+                            if (COUNT) st.v[C_NODE]++;
+                            const f32x2 tx = __builtin_elementwise_fma(f32x2{px.x, px.y}, f32x2{invx, invx}, f32x2{nox, nox});
+                            const f32x2 ty = __builtin_elementwise_fma(f32x2{py.x, py.y}, f32x2{invy, invy}, f32x2{noy, noy});
+                            const f32x2 tz = __builtin_elementwise_fma(f32x2{pz.x, pz.y}, f32x2{invz, invz}, f32x2{noz, noz});
+                            const float tn = fmaxf(fmaxf(tx.x, ty.x), fmaxf(tz.x, kTMin));
+                            const float tf = fminf(fminf(tx.y, ty.y), fminf(tz.y, h.t));
+                            const bool pass = tn <= tf;
+                            idx = pass ? idx + kWalkEntryBytes : (int)(w & 0xFFFFu);
+                            walking = !(pass && w < (kWalkNoLeaf << 16));
+                        }
+                    };
+                    int still;
+                    do {  // three steps per look at the lane count; the look comes before the third step
+                        boxStep();
+                        boxStep();
+                        still = popc64(__ballot(walking));
+                        boxStep();
+                    } while (still >= keep && keep > 0);
+                    if (op == OP_BOX && !walking) {  // left the burst: at a leaf run, or at the end of the walk
+                        const uint32_t first = w >> 16;
+                        p = (int)first;
+                        op = first == kWalkEnd ? afterWalk() : OP_PRIM;
+                    }
+                    lap(T_BOX);
+                } else if (cur == OP_BOX) {
                     // Search structure: conservative fused box test.  An entry that passes and carries
                     // a leaf run sends the lane to PRIM; `idx` already names the entry to go on with.
                     const int keep = boxKeep < nBox ? boxKeep : nBox;  // never spin below what is available
@@ -927,7 +1018,7 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
                             if (bad) {
                                 retraceInReferenceOrder();
                             } else if (ref & kRefLast) {
-                                op = idx >= (mode ? nNodesRef : nNodesFast) ? afterWalk() : (mode ? OP_REFBOX : OP_BOX);
+                                op = idx >= (mode ? nNodesRef : walkEnd) ? afterWalk() : (mode ? OP_REFBOX : OP_BOX);
                             } else {
                                 p += 1;
                             }
@@ -1233,6 +1324,7 @@ __global__ void __launch_bounds__(256) resolveKernel(const float4* payloads, siz
 // ------------------------------------------------------------------ launch wrappers
 template <bool LDS, bool COUNT, bool TIME = false>
 static hipError_t launchWavefrontT(const RenderArgs& a, int blocks, int threads, size_t shmem, hipStream_t stream) {
+    (void)hipGetLastError();  // an earlier, unrelated failure must not be reported as this launch's
     if (LDS)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(renderWavefront<LDS, COUNT, TIME>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
@@ -1245,6 +1337,7 @@ static hipError_t launchWavefrontT(const RenderArgs& a, int blocks, int threads,
 }
 
 hipError_t launchWavefront(const RenderArgs& a, bool lds, bool count, int blocks, int threads, hipStream_t stream) {
+    (void)hipGetLastError();  // an earlier, unrelated failure must not be reported as this launch's
     size_t shmem = lds ? (size_t)a.lds_bytes : 0;
     if (count && a.timing)
         return lds ? launchWavefrontT<true, false, true>(a, blocks, threads, shmem, stream)
@@ -1256,6 +1349,7 @@ hipError_t launchWavefront(const RenderArgs& a, bool lds, bool count, int blocks
 }
 
 hipError_t launchRender(const RenderArgs& a, bool lds, bool count, int blocks, int threads, hipStream_t stream) {
+    (void)hipGetLastError();  // an earlier, unrelated failure must not be reported as this launch's
     size_t shmem = lds ? (size_t)a.lds_bytes : 0;
     if (lds && !count) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(renderKernel<true, false>),
@@ -1275,6 +1369,7 @@ hipError_t launchRender(const RenderArgs& a, bool lds, bool count, int blocks, i
 
 hipError_t launchTrace(const DevScene& sc, int n, const float* rays, int* kind, int* id, float* t, float* normal,
                        int* front, float* uv, hipStream_t stream) {
+    (void)hipGetLastError();  // an earlier, unrelated failure must not be reported as this launch's
     traceKernel<<<(n + 255) / 256, 256, 0, stream>>>(sc, n, rays, kind, id, t, normal, front, uv);
     return hipGetLastError();
 }
@@ -1282,18 +1377,21 @@ hipError_t launchTrace(const DevScene& sc, int n, const float* rays, int* kind, 
 hipError_t launchScatter(const DevScene& sc, int n, const int* mat, const float* rayIn, const float* p, const float* nrm,
                          const int* front, const float* uv, const unsigned int* key4, float* atten, float* rayOut,
                          int* alive, unsigned int* counterOut, hipStream_t stream) {
+    (void)hipGetLastError();  // an earlier, unrelated failure must not be reported as this launch's
     scatterKernel<<<(n + 63) / 64, 64, 0, stream>>>(sc, n, mat, rayIn, p, nrm, front, uv, key4, atten, rayOut, alive,
                                                    counterOut);
     return hipGetLastError();
 }
 
 hipError_t launchReflectance(int n, const float* cosine, const float* refIdx, float* out, hipStream_t stream) {
+    (void)hipGetLastError();  // an earlier, unrelated failure must not be reported as this launch's
     reflectanceKernel<<<(n + 255) / 256, 256, 0, stream>>>(n, cosine, refIdx, out);
     return hipGetLastError();
 }
 
 hipError_t launchResolve(const float4* payloads, size_t stride4, int width, int height, int tiles_per_row_local,
                          int world, int only_rank, int mode, int spp, float4* out32, uint32_t* out8, hipStream_t stream) {
+    (void)hipGetLastError();  // an earlier, unrelated failure must not be reported as this launch's
     dim3 grid((width + 31) / 32, (height + 7) / 8);
     resolveKernel<<<grid, 256, 0, stream>>>(payloads, stride4, width, height, tiles_per_row_local, world, only_rank,
                                             mode, spp, out32, out8);
