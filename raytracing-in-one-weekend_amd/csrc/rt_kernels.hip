@@ -939,7 +939,7 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
                             const f32x2u py = *reinterpret_cast<const f32x2u*>(e + 12 + sy);
                             const f32x2u pz = *reinterpret_cast<const f32x2u*>(e + 24 + sz);
                             w = *reinterpret_cast<const uint32_t*>(e + 36);
-                            if (COUNT) st.v[C_NODE]++;
+                            if (COUNT && idx != walkEnd) st.v[C_NODE]++;  // the closing entry is not a box of the scene
                             const f32x2 tx = __builtin_elementwise_fma(f32x2{px.x, px.y}, f32x2{invx, invx}, f32x2{nox, nox});
                             const f32x2 ty = __builtin_elementwise_fma(f32x2{py.x, py.y}, f32x2{invy, invy}, f32x2{noy, noy});
                             const f32x2 tz = __builtin_elementwise_fma(f32x2{pz.x, pz.y}, f32x2{invz, invz}, f32x2{noz, noz});
