@@ -21,10 +21,6 @@
 namespace rt {
 hipError_t launchRender(const RenderArgs& a, bool lds, bool count, int blocks, int threads, hipStream_t stream);
 hipError_t launchWavefront(const RenderArgs& a, bool lds, bool count, int blocks, int threads, hipStream_t stream);
-hipError_t launchSplit(const RenderArgs& a, int blocks, hipStream_t stream);
-size_t splitLdsBytes();
-int splitSlots();
-int splitThreads();
 hipError_t launchTrace(const DevScene& sc, int n, const float* rays, int* kind, int* id, float* t, float* normal,
                        int* front, float* uv, hipStream_t stream);
 hipError_t launchScatter(const DevScene& sc, int n, const int* mat, const float* rayIn, const float* p, const float* nrm,
@@ -71,8 +67,6 @@ struct rt_context {
     unsigned long long sched_stats[14] = {0};  // from the last rt_count(): {executions, lanes} per operation
     float4* colors = nullptr;  // per-sample radiance of the split mode (grown on demand)
     size_t colors_cap = 0;     // in float4
-    float4* split_state = nullptr;  // per-path shading state of the split loop (RT_KERNEL=split)
-    size_t split_state_cap = 0;     // in float4
     bool device_build = false;  // rt_upload_scene() builds the search structure on the device
     float build_ms = 0.0f;      // device time of the last such build
     void* resolved = nullptr;  // row-major image the read-out calls resolve into (grown on demand, kept)
@@ -240,7 +234,6 @@ int launch(rt_context* ctx, rt::RenderArgs& a, bool count, const Workspace* fixe
         if (!fixed && need > ctx->colors_cap) {
             HIP_TRY(hipStreamSynchronize(ctx->stream));
             if (ctx->colors) (void)hipFree(ctx->colors);
-    if (ctx->split_state) (void)hipFree(ctx->split_state);
             ctx->colors = nullptr;
             ctx->colors_cap = 0;
             HIP_TRY(hipMalloc((void**)&ctx->colors, need * sizeof(float4)));
@@ -254,31 +247,6 @@ int launch(rt_context* ctx, rt::RenderArgs& a, bool count, const Workspace* fixe
         if (blocks > needed) blocks = (int)needed;
         if (blocks < 1) blocks = 1;
         HIP_TRY(hipMemsetAsync(a.queue, 0, 256, ctx->stream));
-        // RT_KERNEL=split: trace waves and shade waves (scenes staged in LDS, plain renders only)
-        const size_t splitLds = rt::ldsSceneBytes(ctx->dsc, ctx->lds_refs, false) + rt::splitLdsBytes();
-        if (kernel && std::strcmp(kernel, "split") == 0 && ctx->use_lds && !count && !fixed && splitLds <= 79 * 1024) {
-            const int splitBlocks = ctx->n_cus * envInt("RT_BLOCKS_PER_CU", 2);
-            const size_t needState = (size_t)splitBlocks * (size_t)rt::splitSlots() * 2;
-            if (needState > ctx->split_state_cap) {
-                HIP_TRY(hipStreamSynchronize(ctx->stream));
-                if (ctx->split_state) (void)hipFree(ctx->split_state);
-                ctx->split_state = nullptr;
-                ctx->split_state_cap = 0;
-                HIP_TRY(hipMalloc((void**)&ctx->split_state, needState * sizeof(float4)));
-                ctx->split_state_cap = needState;
-            }
-            a.split_state = ctx->split_state;
-            a.split_trace_waves = envInt("RT_SPLIT_TRACE_WAVES", 8);
-            a.split_swap_min = envInt("RT_SPLIT_SWAP_MIN", 16);
-            // paths per workgroup: every trace lane busy and a few batches waiting; at least one batch's worth
-            // of slots must stay free, or finished walks find no slot to go to
-            a.split_paths = std::min(envInt("RT_SPLIT_PATHS", 64 * a.split_trace_waves + 320),
-                                     64 * a.split_trace_waves + rt::splitSlots() - 128);
-            a.lds_bytes = (int)splitLds;
-            HIP_TRY(rt::launchSplit(a, splitBlocks, ctx->stream));
-            a.lds_bytes = (int)ctx->lds_need;
-            continue;
-        }
         HIP_TRY(rt::launchWavefront(a, ctx->use_lds, count, blocks, wfThreads, ctx->stream));
     }
     return RT_OK;

@@ -54,10 +54,6 @@ struct RenderArgs {
     // per-sample radiance of the launch: colors[(sample - first_sample) * n_slots + pixel slot],
     // added to the accumulation buffer in sample order by accumulateColors()
     float4* colors;
-    // split loop only: what its shading waves keep per path (2 x float4 per slot per workgroup), how many
-    // of a workgroup's waves trace, and from how many waiting lanes on a trace wave swaps rays
-    float4* split_state;
-    int split_trace_waves, split_swap_min, split_paths;
 };
 
 // Megabytes of the fixed colour scratch behind rt_render_noalloc() (one copy per GPU in use).
@@ -78,11 +74,11 @@ constexpr int kTile = 8;  // one wave64 = one 8x8 pixel tile
 // re-trace), which lets one more workgroup share a CU's LDS.
 // The search structure is budgeted at 40 bytes per entry plus one closing entry, which is how the
 // persistent kernel lays it out (the plain kernel stages 32 bytes per entry into the same space).
-inline size_t ldsSceneBytes(const DevScene& s, bool with_reference_arrays = true, bool with_materials = true) {
+inline size_t ldsSceneBytes(const DevScene& s, bool with_reference_arrays = true) {
     auto al = [](size_t x) { return (x + 15) & ~size_t(15); };
     size_t n = al(((size_t)s.n_fast_nodes + 1) * 40) + al((size_t)s.n_fast_refs * 4) + al((size_t)s.n_spheres * 16) +
                al((size_t)s.n_tris * 48) + al((size_t)s.n_spheres * 4) + al((size_t)s.n_tris * 4) +
-               (with_materials ? al((size_t)s.n_mats * 32) : 0) + al((size_t)s.n_spheres * 4) + al((size_t)s.n_tris * 4);
+               al((size_t)s.n_mats * 32) + al((size_t)s.n_spheres * 4) + al((size_t)s.n_tris * 4);
     if (with_reference_arrays)
         n += al((size_t)s.n_nodes * 32) + al((size_t)s.n_prim_refs * 4) + al((size_t)s.n_prim_refs * 4) +
              al((size_t)s.n_nodes * 4);

@@ -591,8 +591,7 @@ constexpr int kWalkEntryBytes = 40;
 constexpr uint32_t kWalkNoLeaf = 0xFFFFu, kWalkEnd = 0xFFFEu;
 
 // Stages the scene tables into LDS and returns views into it (layout = ldsSceneBytes()).
-__device__ __forceinline__ SceneView stageScene(const DevScene& sc, bool withReferenceArrays, bool walkEntries = false,
-                                                bool materialsInLds = true, int* usedBytes = nullptr) {
+__device__ __forceinline__ SceneView stageScene(const DevScene& sc, bool withReferenceArrays, bool walkEntries = false) {
     char* base = reinterpret_cast<char*>(rt_lds);
     int off = 0;
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -646,7 +645,7 @@ __device__ __forceinline__ SceneView stageScene(const DevScene& sc, bool withRef
     v.tris = take16(sc.tri_isect, sc.n_tris * 3);
     v.sphere_mat = take4i(sc.sphere_mat, sc.n_spheres);
     v.tri_mat = take4i(sc.tri_mat, sc.n_tris);
-    v.materials = materialsInLds ? take16(sc.materials, sc.n_mats * 2) : sc.materials;
+    v.materials = take16(sc.materials, sc.n_mats * 2);
     v.sphere_ord = take4i(sc.sphere_ord, sc.n_spheres);
     v.tri_ord = take4i(sc.tri_ord, sc.n_tris);
     if (withReferenceArrays) {
@@ -660,7 +659,6 @@ __device__ __forceinline__ SceneView stageScene(const DevScene& sc, bool withRef
         v.prim_guard = sc.prim_guard;
         v.node_outer = sc.node_outer;
     }
-    if (usedBytes) *usedBytes = off;
     __syncthreads();
     return v;
 }
@@ -766,9 +764,6 @@ __device__ __forceinline__ int popc64(unsigned long long m) {
 // (64 registers, heavy spilling) 60 ms.
 #ifndef WF_BOUNDS
 #define WF_BOUNDS 512, 6
-#endif
-#ifndef WF_SPLIT_THREADS
-#define WF_SPLIT_THREADS 768
 #endif
 // TIME (diagnostic): instead of path counters, each wave adds up its clock ticks per operation
 // -- box bursts, primitive runs, SHADE, NEWPATH, reference-order box steps, and everything else
@@ -1195,457 +1190,6 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
     }
 }
 
-// ---------------------------------------------------------------------------------------
-// Split loop (scenes staged in LDS): the waves of a workgroup specialise.
-//
-// In the loop above every lane carries one path through all its operations, and an operation runs
-// for the lanes that happen to want it: SHADE and NEWPATH, the two long ones, execute with about half
-// the wave.  Here a workgroup keeps `kSplitSlots` paths, more than it has lanes, and its waves divide
-// the work: TRACE waves walk the search structure and test primitives, nothing else; SHADE waves turn
-// hits into scattered rays, finish paths and start new ones, always a full wave at a time.  A path is
-// a forty-byte slot in LDS {origin, direction, t, primitive, barycentrics} plus what only shading
-// needs (throughput, random stream, depth, unit: 32 bytes in a per-workgroup array in global memory,
-// written and read by the shading waves alone).  Slot numbers travel through three rings in LDS:
-// rays to trace, hits to shade, and slots whose path has ended and that want a new one.  A trace lane
-// owns its slot while it walks; when the walk is over it writes the hit into the slot, hands the slot
-// to the hit ring and takes the next ray.  Which wave computes what never changes a result: a path's
-// random stream is keyed by (x, y, sample, counter) and travels with it.
-//
-// Rings: producers reserve room with one atomic add per wave, write their cells, and publish in
-// reservation order (`com`); consumers claim published cells with a compare-and-swap on `head`.  A
-// ring has more cells than there are slots, so it never overflows and producers never wait for room.
-constexpr int kSplitSlots = 896;
-constexpr int kSplitRing = 1024;  // cells per ring, a power of two >= kSplitSlots
-constexpr int kSlotDwords = 10;
-struct SplitRing {
-    unsigned int res, com, head, pad;
-};
-struct SplitShared {
-    SplitRing ray, hit, fresh;
-    int live;   // slots not yet retired
-    int error;  // a wave gave up waiting: everybody leaves
-    int pad[2];
-};
-enum : int { T_BOXOP = 0, T_PRIMOP = 1, T_REFOP = 2, T_FIN = 3, T_IDLE = 4 };
-
-__device__ __forceinline__ unsigned int ldsLoad(const unsigned int* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-__device__ __forceinline__ int ldsLoad(const int* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-
-// LDS traffic of this wave issued so far is done; nothing is moved across by the compiler.
-__device__ __forceinline__ void ldsFence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-
-// Every lane of the wave calls this (uniform control flow); lanes with `mine` hand over `slot`.
-// GLOBAL_TOO: what the wave stored to global memory must be visible to the consumer as well (the
-// shading state of a path); otherwise only LDS is involved, which executes a wave's accesses in order.
-template <bool GLOBAL_TOO>
-__device__ __forceinline__ void ringPush(SplitRing* q, uint16_t* cells, bool mine, int slot, int lane, int* error) {
-    const unsigned long long m = __ballot(mine);
-    if (m == 0) return;
-    const int k = popc64(m);
-    unsigned int pos = 0;
-    if (lane == 0) pos = __hip_atomic_fetch_add(&q->res, (unsigned int)k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    pos = __builtin_amdgcn_readfirstlane(pos);
-    if (mine) {
-        const int r = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-        cells[(pos + (unsigned int)r) & (kSplitRing - 1)] = (uint16_t)slot;
-    }
-    // the slots' contents and the cells are in place before the cells are published
-    if (GLOBAL_TOO)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    else
-        ldsFence();
-    if (lane == 0) {
-        int spins = 0;
-        while (ldsLoad(&q->com) != pos) {  // earlier reservations publish first
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1 << 20)) {
-                __hip_atomic_store(error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                break;
-            }
-        }
-        __hip_atomic_store(&q->com, pos + (unsigned int)k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-}
-
-// Claims up to `want` published cells for the wave; returns how many, and lanes with index < that get a slot.
-template <bool GLOBAL_TOO>
-__device__ __forceinline__ int ringPop(SplitRing* q, const uint16_t* cells, int want, int index, int lane, int& slot) {
-    unsigned int h = 0, take = 0;
-    if (lane == 0 && want > 0) {
-        for (;;) {
-            h = ldsLoad(&q->head);
-            const unsigned int avail = ldsLoad(&q->com) - h;
-            take = avail < (unsigned int)want ? avail : (unsigned int)want;
-            if (take == 0) break;
-            unsigned int expected = h;
-            if (__hip_atomic_compare_exchange_strong(&q->head, &expected, h + take, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                     __HIP_MEMORY_SCOPE_WORKGROUP))
-                break;
-        }
-    }
-    h = __builtin_amdgcn_readfirstlane(h);
-    take = __builtin_amdgcn_readfirstlane(take);
-    if (GLOBAL_TOO)
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    else
-        ldsFence();
-    if (index >= 0 && index < (int)take) slot = cells[(h + (unsigned int)index) & (kSplitRing - 1)];
-    return (int)take;
-}
-
-__device__ __forceinline__ int ringCount(const SplitRing* q) {
-    return (int)(ldsLoad(&q->com) - ldsLoad(&q->head));
-}
-
-__global__ void __launch_bounds__(WF_SPLIT_THREADS, 6) renderSplit(RenderArgs a) {
-    const DevScene& sc = a.sc;
-    fillCounterLut();
-    int sceneBytes = 0;
-    SceneView sv = stageScene(sc, a.knob[2] != 0, true, false, &sceneBytes);
-    char* area = reinterpret_cast<char*>(rt_lds) + ((sceneBytes + 15) & ~15);
-    SplitShared* sh = reinterpret_cast<SplitShared*>(area);
-    uint16_t* rayCells = reinterpret_cast<uint16_t*>(area + sizeof(SplitShared));
-    uint16_t* hitCells = rayCells + kSplitRing;
-    uint16_t* freshCells = hitCells + kSplitRing;
-    float* slots = reinterpret_cast<float*>(freshCells + kSplitRing);
-    for (int i = threadIdx.x; i < kSplitSlots; i += blockDim.x) freshCells[i] = (uint16_t)i;  // every slot wants a path
-    if (threadIdx.x == 0) {
-        sh->ray = SplitRing{0u, 0u, 0u, 0u};
-        sh->hit = SplitRing{0u, 0u, 0u, 0u};
-        sh->fresh = SplitRing{(unsigned int)kSplitSlots, (unsigned int)kSplitSlots, 0u, 0u};
-        sh->live = kSplitSlots;
-        sh->error = 0;
-    }
-    __syncthreads();
-
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int nTrace = a.split_trace_waves;
-    float4* pathState = a.split_state + (size_t)blockIdx.x * kSplitSlots * 2;
-    const int nNodesRef = sc.n_nodes;
-    const int walkEnd = sc.n_fast_nodes * kWalkEntryBytes;
-    const float originLimit = sc.origin_limit;
-
-    if (wave < nTrace) {
-        // ------------------------------------------------------------ trace wave
-        const int boxKeep = a.knob[0], primKeep = a.knob[3];
-        const int swapMin = a.split_swap_min;
-        int op = T_IDLE, slot = 0, idx = 0, p = 0, mode = 0;
-        Ray r{{0.f, 0.f, 0.f}, {0.f, 0.f, 1.f}};
-        float invx = 0.f, invy = 0.f, invz = 0.f, aa = 1.f, nox = 0.f, noy = 0.f, noz = 0.f;
-        Hit h{0.f, kNoHit, 0.f, 0.f};
-        int starve = 0, dry = 0;
-        auto walkOver = [&]() { return T_FIN; };
-        for (;;) {
-            const int cBox = popc64(__ballot(op == T_BOXOP)), cPrim = popc64(__ballot(op == T_PRIMOP)),
-                      cRef = popc64(__ballot(op == T_REFOP)), cFin = popc64(__ballot(op == T_FIN));
-            const int cWalk = cBox + cPrim + cRef;
-            if (ldsLoad(&sh->error)) break;
-            if (cWalk == 0 && cFin == 0 && ldsLoad(&sh->live) <= 0) break;
-            const int cIdle = 64 - cWalk - cFin;
-            if (cWalk == 0 || cFin >= swapMin || (starve == 0 && cFin + cIdle >= swapMin)) {
-                // hand over finished walks, take new rays.  First the guard test of the search-structure walks
-                // that found something (this lane holds the reciprocals): a hit that cannot be vouched for
-                // is looked for again in the reference's order
-                if (op == T_FIN && mode == 0 && h.ref != kNoHit && !guardsPass<false>(sv, r, invx, invy, invz, h, nullptr)) {
-                    h.t = __builtin_inff();
-                    h.ref = kNoHit;
-                    idx = 0;
-                    mode = 1;
-                    op = T_REFOP;
-                }
-                if (op == T_FIN) {
-                    float* s = slots + slot * kSlotDwords;
-                    s[6] = h.t;
-                    s[7] = __uint_as_float(h.ref);
-                    s[8] = h.bu;
-                    s[9] = h.bv;
-                }
-                ringPush<false>(&sh->hit, hitCells, op == T_FIN, slot, lane, &sh->error);
-                if (op == T_FIN) op = T_IDLE;
-                const unsigned long long idle = __ballot(op == T_IDLE);
-                const int index = op == T_IDLE
-                                      ? __builtin_amdgcn_mbcnt_hi((unsigned)(idle >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)idle, 0u))
-                                      : -1;
-                int got = 0, mine = -1;
-                got = ringPop<false>(&sh->ray, rayCells, popc64(idle), index, lane, mine);
-                if (index >= 0 && index < got) {
-                    slot = mine;
-                    const float* s = slots + slot * kSlotDwords;
-                    r.o = V3{s[0], s[1], s[2]};
-                    r.d = V3{s[3], s[4], s[5]};
-                    invx = 1.0f / r.d.x;
-                    invy = 1.0f / r.d.y;
-                    invz = 1.0f / r.d.z;
-                    aa = dot(r.d, r.d);
-                    h.t = __builtin_inff();
-                    h.ref = kNoHit;
-                    idx = 0;
-                    nox = -(r.o.x * invx);
-                    noy = -(r.o.y * invy);
-                    noz = -(r.o.z * invz);
-                    mode = (sc.force_ref || !fastTestUsable(r.o, originLimit, invx, invy, invz, nox, noy, noz)) ? 1 : 0;
-                    op = mode ? T_REFOP : T_BOXOP;
-                }
-                if (got == 0) {
-                    starve = 4;  // nothing to take: walk on for a while before asking again
-                    if (cWalk == 0) {
-                        __builtin_amdgcn_s_sleep(8);
-                        if (++dry > (1 << 18)) {
-                            if (lane == 0) __hip_atomic_store(&sh->error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            break;
-                        }
-                    }
-                } else {
-                    dry = 0;
-                }
-                continue;
-            }
-            if (starve > 0) starve -= 1;
-            // one traversal phase, as in the loop above: box bursts and primitive steps take turns
-            int cur = T_BOXOP, best = cBox;
-            if (cRef > best) { best = cRef; cur = T_REFOP; }
-            if (cPrim > best) { best = cPrim; cur = T_PRIMOP; }
-            if (cur == T_BOXOP) {
-                const int keep = boxKeep < cBox ? boxKeep : cBox;
-                const uint32_t sx = (fbits(invx) >> 29) & 4u, sy = (fbits(invy) >> 29) & 4u, sz = (fbits(invz) >> 29) & 4u;
-                bool walking = op == T_BOXOP;
-                uint32_t w = 0;
-                auto boxStep = [&]() {
-                    if (walking) {
-                        const char* e = sv.wnodes + idx;
-                        const f32x2u px = *reinterpret_cast<const f32x2u*>(e + sx);
-                        const f32x2u py = *reinterpret_cast<const f32x2u*>(e + 12 + sy);
-                        const f32x2u pz = *reinterpret_cast<const f32x2u*>(e + 24 + sz);
-                        w = *reinterpret_cast<const uint32_t*>(e + 36);
-                        const f32x2 tx = __builtin_elementwise_fma(f32x2{px.x, px.y}, f32x2{invx, invx}, f32x2{nox, nox});
-                        const f32x2 ty = __builtin_elementwise_fma(f32x2{py.x, py.y}, f32x2{invy, invy}, f32x2{noy, noy});
-                        const f32x2 tz = __builtin_elementwise_fma(f32x2{pz.x, pz.y}, f32x2{invz, invz}, f32x2{noz, noz});
-                        const float tn = fmaxf(fmaxf(tx.x, ty.x), fmaxf(tz.x, kTMin));
-                        const float tf = fminf(fminf(tx.y, ty.y), fminf(tz.y, h.t));
-                        const bool pass = tn <= tf;
-                        idx = pass ? idx + kWalkEntryBytes : (int)(w & 0xFFFFu);
-                        walking = !(pass && w < (kWalkNoLeaf << 16));
-                    }
-                };
-                int still;
-                do {
-                    boxStep();
-                    boxStep();
-                    still = popc64(__ballot(walking));
-                    boxStep();
-                } while (still >= keep && keep > 0);
-                if (op == T_BOXOP && !walking) {
-                    const uint32_t first = w >> 16;
-                    p = (int)first;
-                    op = first == kWalkEnd ? walkOver() : T_PRIMOP;
-                }
-            } else if (cur == T_PRIMOP) {
-                do {
-                    if (op == T_PRIMOP) {
-                        const uint32_t ref = (mode ? sv.refs : sv.frefs)[p];
-                        bool bad = false;
-                        float t, u = mode ? h.bu : 0.0f, v = mode ? h.bv : 0.0f;
-                        if (primRoot<false>(sv, ref, r, aa, mode ? h.t : __builtin_inff(), t, u, v, nullptr)) {
-                            bool take = true;
-                            if (!mode) {
-                                bad = t != t;
-                                take = !bad && (h.ref == kNoHit || t < h.t || (t == h.t && refOrder(sv, ref) > refOrder(sv, h.ref)));
-                            }
-                            if (take) {
-                                h.t = t;
-                                h.ref = ref & ~kRefLast;
-                                h.bu = u;
-                                h.bv = v;
-                            }
-                        }
-                        if (bad) {  // a distance that cannot be ordered: again, in the reference's order
-                            h.t = __builtin_inff();
-                            h.ref = kNoHit;
-                            idx = 0;
-                            mode = 1;
-                            op = T_REFOP;
-                        } else if (ref & kRefLast) {
-                            op = idx >= (mode ? nNodesRef : walkEnd) ? walkOver() : (mode ? T_REFOP : T_BOXOP);
-                        } else {
-                            p += 1;
-                        }
-                    }
-                } while (popc64(__ballot(op == T_PRIMOP)) >= primKeep);
-            } else {
-                const int keep = boxKeep < cRef ? boxKeep : cRef;
-                do {
-                    if (op == T_REFOP) {
-                        const float4 n0 = sv.nodes[2 * idx], n1 = sv.nodes[2 * idx + 1];
-                        const uint32_t w3 = fbits(n0.w);
-                        const int first = (int)fbits(n1.w);
-                        const bool nobox = (w3 & kNoBox) != 0;
-                        const bool pass = slabPass(n0, n1, r, invx, invy, invz, h.t) || nobox;
-                        idx = pass ? idx + 1 : (int)(w3 & kSkipMask);
-                        if (pass && first >= 0) {
-                            p = first;
-                            op = T_PRIMOP;
-                        } else if (idx >= nNodesRef) {
-                            op = walkOver();
-                        }
-                    }
-                } while (popc64(__ballot(op == T_REFOP)) >= keep && keep > 0);
-            }
-        }
-        return;
-    }
-
-    // ---------------------------------------------------------------- shade wave
-    const int nTiles = a.n_local_tiles;
-    const unsigned int nChunks = (unsigned int)nTiles * (unsigned int)a.n_samples;
-    int chunk = 0, chunkNext = 64, chunkSample = 0, chunkX0 = 0, chunkY0 = 0;
-    bool chunkInside = false;
-    const bool pollsHost = wave == nTrace;
-    unsigned int fetches = 15;
-    auto fetchChunk = [&]() {  // lane 0 only
-        unsigned int c = atomicAdd(a.queue, 1u);
-        if (a.cancel) {
-            if (pollsHost && (++fetches & 15u) == 0u && __hip_atomic_load(a.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM))
-                __hip_atomic_store(&g_cancelSeen, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (__hip_atomic_load(&g_cancelSeen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
-                a.queue[1] = 1u;
-                c = 0xFFFFFFFFu;
-            }
-        }
-        return c;
-    };
-    int patience = 0, dry = 0;
-    for (;;) {
-        if (ldsLoad(&sh->live) <= 0 || ldsLoad(&sh->error)) break;
-        const int nHit = ringCount(&sh->hit), nFresh = ringCount(&sh->fresh);
-        const bool eager = patience > 3;  // waited long enough for a full wave's worth
-        if (nHit >= 64 || (eager && nHit > 0 && nHit >= nFresh)) {
-            patience = 0;
-            dry = 0;
-            int slot = 0;
-            const int got = ringPop<true>(&sh->hit, hitCells, 64, lane, lane, slot);
-            bool toRay = false, toFresh = false;
-            if (lane < got) {
-                float* s = slots + slot * kSlotDwords;
-                Ray r{{s[0], s[1], s[2]}, {s[3], s[4], s[5]}};
-                const Hit h{s[6], __float_as_uint(s[7]), s[8], s[9]};
-                const float4 q0 = pathState[2 * slot], q1 = pathState[2 * slot + 1];
-                V3 thr{q0.x, q0.y, q0.z};
-                Rng rng{__float_as_uint(q0.w), __float_as_uint(q1.x)};
-                int depth = (int)__float_as_uint(q1.y);
-                const unsigned int unit = __float_as_uint(q1.z);
-                V3 terminal{0.f, 0.f, 0.f};
-                bool ended = true;
-                if (h.ref == kNoHit) {
-                    terminal = V3{sc.bg[0], sc.bg[1], sc.bg[2]};
-                } else {
-                    const Surface sf = surfaceAt(sc, sv, r, h);
-                    Ray out;
-                    V3 atten, emit;
-                    if (!scatter<false>(sc, sv, r, sf, rng, out, atten, emit, nullptr)) {
-                        terminal = emit;
-                    } else {
-                        thr = thr * atten;
-                        depth -= 1;
-                        if (depth > 0) {
-                            ended = false;
-                            s[0] = out.o.x; s[1] = out.o.y; s[2] = out.o.z;
-                            s[3] = out.d.x; s[4] = out.d.y; s[5] = out.d.z;
-                            pathState[2 * slot] = make_float4(thr.x, thr.y, thr.z, __uint_as_float(rng.key));
-                            pathState[2 * slot + 1] = make_float4(__uint_as_float(rng.counter), __uint_as_float((uint32_t)depth),
-                                                                  __uint_as_float(unit), 0.f);
-                        }
-                    }
-                }
-                if (ended) {
-                    const V3 c = thr * terminal;
-                    a.colors[unit] = make_float4(c.x, c.y, c.z, 0.f);
-                }
-                toRay = !ended;
-                toFresh = ended;
-            }
-            ringPush<false>(&sh->fresh, freshCells, toFresh, slot, lane, &sh->error);
-            ringPush<true>(&sh->ray, rayCells, toRay, slot, lane, &sh->error);
-        } else if (nFresh >= 64 || (eager && nFresh > 0)) {
-            patience = 0;
-            dry = 0;
-            int slot = 0;
-            const int got = ringPop<false>(&sh->fresh, freshCells, 64, lane, lane, slot);
-            if (got > 0 && chunk >= 0 && chunkNext >= 64) {  // the next 64 units
-                unsigned int c = 0;
-                if (lane == 0) c = fetchChunk();
-                c = __builtin_amdgcn_readfirstlane(c);
-                if (c >= nChunks) {
-                    chunk = -1;
-                } else {
-                    chunk = (int)c;
-                    chunkNext = 0;
-                    const int sIdx = (int)(c / (unsigned int)nTiles);
-                    const int tile = (int)(c - (unsigned int)sIdx * (unsigned int)nTiles);
-                    const int ty = tile / a.tiles_per_row_local;
-                    const int k = tile - ty * a.tiles_per_row_local;
-                    int base = (a.rank - ty) % a.world;
-                    if (base < 0) base += a.world;
-                    const int tx = base + k * a.world;
-                    chunkSample = a.first_sample + sIdx;
-                    chunkX0 = tx * kTile;
-                    chunkY0 = ty * kTile;
-                    chunkInside = tx < a.tiles_x;
-                }
-            }
-            bool toRay = false, again = false, retire = false;
-            if (lane < got) {
-                const int l = chunkNext + lane;
-                if (chunk < 0) {
-                    retire = true;  // no units left: the slot goes out of use
-                } else if (l >= 64) {
-                    again = true;  // the chunk ran out before this slot's turn
-                } else {
-                    const int px = chunkX0 + (l & 7), py = chunkY0 + (l >> 3);
-                    const unsigned int unit = (unsigned int)chunk * 64u + (unsigned int)l;
-                    again = true;
-                    if (chunkInside && px < a.width && py < a.height) {
-                        Rng rng;
-                        rng.init((uint32_t)px, (uint32_t)py, chunkSample);
-                        float u = ((float)px + rng.next()) / (float)(a.width - 1);
-                        float v = ((float)py + rng.next()) / (float)(a.height - 1);
-                        const Ray r = cameraRay(sc, u, v, rng);
-                        if (a.max_depth <= 0) {
-                            a.colors[unit] = make_float4(0.f, 0.f, 0.f, 0.f);
-                        } else {
-                            float* s = slots + slot * kSlotDwords;
-                            s[0] = r.o.x; s[1] = r.o.y; s[2] = r.o.z;
-                            s[3] = r.d.x; s[4] = r.d.y; s[5] = r.d.z;
-                            pathState[2 * slot] = make_float4(1.f, 1.f, 1.f, __uint_as_float(rng.key));
-                            pathState[2 * slot + 1] = make_float4(__uint_as_float(rng.counter), __uint_as_float((uint32_t)a.max_depth),
-                                                                  __uint_as_float(unit), 0.f);
-                            again = false;
-                            toRay = true;
-                        }
-                    }
-                }
-            }
-            if (chunk >= 0) chunkNext += got;
-            const int nRetire = popc64(__ballot(retire));
-            if (nRetire && lane == 0) __hip_atomic_fetch_add(&sh->live, -nRetire, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            ringPush<false>(&sh->fresh, freshCells, again, slot, lane, &sh->error);
-            ringPush<true>(&sh->ray, rayCells, toRay, slot, lane, &sh->error);
-        } else {
-            patience += 1;
-            __builtin_amdgcn_s_sleep(4);
-            if (++dry > (1 << 18)) {
-                if (lane == 0) __hip_atomic_store(&sh->error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                break;
-            }
-        }
-    }
-    if (lane == 0 && ldsLoad(&sh->error) && a.queue) a.queue[2] = 1u;  // reported by the host after the launch
-}
-
 // Second step of a render launch: accum[q] += colors[s * n_slots + q] for the launch's samples in
 // order (the reference's `pixelColor +=` order, R/src/Core/Raytracer.cpp:84-90); .w = samples so far.
 __global__ void __launch_bounds__(256) accumulateColors(RenderArgs a) {
@@ -1802,23 +1346,6 @@ hipError_t launchWavefront(const RenderArgs& a, bool lds, bool count, int blocks
                           : launchWavefrontT<true, false>(a, blocks, threads, shmem, stream);
     return count ? launchWavefrontT<false, true>(a, blocks, threads, 0, stream)
                  : launchWavefrontT<false, false>(a, blocks, threads, 0, stream);
-}
-
-// Bytes of LDS the split loop needs after the staged scene tables: ring counters, three rings, the path slots.
-size_t splitLdsBytes() { return sizeof(SplitShared) + 3 * kSplitRing * sizeof(uint16_t) + (size_t)kSplitSlots * kSlotDwords * 4; }
-int splitSlots() { return kSplitSlots; }
-int splitThreads() { return WF_SPLIT_THREADS; }
-
-hipError_t launchSplit(const RenderArgs& a, int blocks, hipStream_t stream) {
-    (void)hipGetLastError();  // an earlier, unrelated failure must not be reported as this launch's
-    const size_t shmem = (size_t)a.lds_bytes;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(renderSplit), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    renderSplit<<<blocks, WF_SPLIT_THREADS, shmem, stream>>>(a);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    const int nSlots = a.n_local_tiles * 64;
-    accumulateColors<<<(nSlots + 255) / 256, 256, 0, stream>>>(a);
-    return hipGetLastError();
 }
 
 hipError_t launchRender(const RenderArgs& a, bool lds, bool count, int blocks, int threads, hipStream_t stream) {
