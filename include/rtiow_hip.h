@@ -157,6 +157,15 @@ int rt_scene_set_camera(rt_scene* s, const float* lookfrom3, const float* lookat
  * u, v, w (3 floats each), lensRadius. */
 int rt_scene_get_camera(const rt_scene* s, float* out22);
 int rt_scene_set_background(rt_scene* s, float r, float g, float b); /* Scene::background */
+/* Normal mapping for PBR materials that carry a normal map.  Off (default): as the reference renders,
+ * whose PBRMaterial::scatter forms the mapped normal and then overwrites it with rec.normal
+ * ("Normalmapping doesn't work properly yet", R/src/Material/Material.h:123-140).  On: the mapped
+ * normal normalize(TBN * (2 texel - 1)) is used for the reflection, the diffuse direction and the
+ * facing test, with the per-triangle tangent frame of R/src/Core/Hittable.h:110-125 (each uv
+ * difference paired with the edge to the same vertex) and the shading normal; the normal map's
+ * texels are read as byte / 255, not through the gamma map meant for colours.  Changes the image,
+ * so it has no counterpart output in the reference; takes effect at the next rt_upload_scene(). */
+int rt_scene_set_normal_mapping(rt_scene* s, int on);
 
 /* ------------------------------------------------- flattened scene (host, for inspection) */
 

@@ -271,6 +271,8 @@ struct HitRecord {  // R/src/Core/Hittable.h:10-28 (tangent/bitangent/modelMatri
     float t = 0;
     bool frontFace = false;  // uninitialised in the reference; defined false here
     float u = 0, v = 0;
+    vec3 tangent, bitangent;  // per-triangle frame (normal mapping, an option the reference does not have working)
+    bool hasFrame = false;
     int primKind = -1, primId = -1;  // bookkeeping for hit-index parity (0 sphere, 1 triangle)
     void setFaceNormal(const Ray& r, vec3 outward) {
         frontFace = glmx::dot(r.direction, outward) < 0;
@@ -297,6 +299,16 @@ struct Texture {  // R/src/Material/Texture.h:4-48 with stb_image.h:1840-1861's 
         const uint8_t* p = &rgb[(size_t)idx * 3];
         return {lut[p[0]], lut[p[1]], lut[p[2]]};
     }
+    vec3 AtLinear(float uCoord, float vCoord) const {  // the same texel as byte / 255 (normal maps hold directions)
+        int texelX = (int)((uCoord * w) - 0.5f);
+        int texelY = (int)(((1 - vCoord) * h) - 0.5f);
+        long idx = (long)texelY * h + texelX;
+        long n = (long)w * h;
+        if (idx < 0) idx = 0;
+        if (idx >= n) idx = n - 1;
+        const uint8_t* p = &rgb[(size_t)idx * 3];
+        return {(float)p[0] / 255.0f, (float)p[1] / 255.0f, (float)p[2] / 255.0f};
+    }
 };
 
 struct Material {  // R/src/Material/Material.h
@@ -305,6 +317,7 @@ struct Material {  // R/src/Material/Material.h
     float param = 0;   // fuzz or ir
     const Texture *diffuse = nullptr, *rough = nullptr, *normalTex = nullptr;
     int id = -1, texD = -1, texR = -1, texN = -1;
+    const bool* normalMapping = nullptr;  // the scene's switch
 
     vec3 emitted() const { return kind == LIGHT ? albedo : vec3(0, 0, 0); }  // :12-14, :108-110
 
@@ -354,6 +367,15 @@ struct Material {  // R/src/Material/Material.h
             case PBR: {  // :121-160; the normal-map branch is overwritten at :140, so it is skipped
                 if (rng.cnt) rng.cnt->scatterPbr++;
                 vec3 normal = rec.normal;
+                // option (off by default): use the mapped normal the reference computes at :123-138 and drops
+                // at :140 -- normalize(TBN * (2 texel - 1)), unit tangent / bitangent of the triangle, unit normal
+                if (normalMapping && *normalMapping && normalTex && rec.hasFrame) {
+                    vec3 T = normalize(rec.tangent), B = normalize(rec.bitangent), N = normalize(rec.normal);
+                    vec3 c = normalTex->AtLinear(rec.u, rec.v);
+                    vec3 m(c.x * 2.0f - 1.0f, c.y * 2.0f - 1.0f, c.z * 2.0f - 1.0f);
+                    normal = normalize(vec3((T.x * m.x + B.x * m.y) + N.x * m.z, (T.y * m.x + B.y * m.y) + N.y * m.z,
+                                            (T.z * m.x + B.z * m.y) + N.z * m.z));
+                }
                 attenuation = diffuse->At(rec.u, rec.v);
                 if (rough) {
                     vec3 reflected = reflect(normalize(rIn.direction), normal);
@@ -419,6 +441,35 @@ struct Triangle : Hittable {  // Hittable.h:46-220
         } else {
             rec.u = u;
             rec.v = v;
+        }
+        // tangent frame from the uv deltas (Hittable.h:110-125, each uv difference paired with the edge to the
+        // same vertex); only the normal-mapping option reads it
+        rec.hasFrame = false;
+        if (vertices[0].textureCoord.x != -1.0f) {
+            const float du1 = vertices[1].textureCoord.x - vertices[0].textureCoord.x,
+                        dv1 = vertices[1].textureCoord.y - vertices[0].textureCoord.y,
+                        du2 = vertices[2].textureCoord.x - vertices[0].textureCoord.x,
+                        dv2 = vertices[2].textureCoord.y - vertices[0].textureCoord.y;
+            const float det = du1 * dv2 - du2 * dv1;
+            const float ff = 1.0f / det;
+            if (det != 0.0f && std::isfinite(det) && std::isfinite(ff)) {
+                float T[3], B[3];
+                bool anyT = false, anyB = false, fin = true;
+                for (int k = 0; k < 3; k++) {
+                    const float e1 = vertices[1].position[k] - vertices[0].position[k],
+                                e2 = vertices[2].position[k] - vertices[0].position[k];
+                    T[k] = ff * (dv2 * e1 - dv1 * e2);
+                    B[k] = ff * (-du2 * e1 + du1 * e2);
+                    anyT = anyT || T[k] != 0.0f;
+                    anyB = anyB || B[k] != 0.0f;
+                    fin = fin && std::isfinite(T[k]) && std::isfinite(B[k]);
+                }
+                if (anyT && anyB && fin) {
+                    rec.tangent = vec3(T[0], T[1], T[2]);
+                    rec.bitangent = vec3(B[0], B[1], B[2]);
+                    rec.hasFrame = true;
+                }
+            }
         }
         rec.mat = mat;
         rec.primKind = 1;
@@ -656,6 +707,7 @@ struct Scene {
     HittableList world;
     Camera camera;
     vec3 background;
+    bool normalMapping = false;
     std::vector<std::unique_ptr<Material>> materials;
     std::vector<std::unique_ptr<Texture>> textures;
     int nSpheres = 0, nTriangles = 0;
@@ -671,6 +723,7 @@ struct Scene {
         m->albedo = a;
         m->param = p;
         m->id = (int)materials.size();
+        m->normalMapping = &normalMapping;
         materials.push_back(std::move(m));
         return materials.back().get();
     }
@@ -945,6 +998,7 @@ void orc_get_camera(void* s, float* out22) {
     out22[21] = c.lensRadius;
 }
 void orc_set_background(void* s, float r, float g, float b) { ((Scene*)s)->background = vec3(r, g, b); }
+void orc_set_normal_mapping(void* s, int on) { ((Scene*)s)->normalMapping = on != 0; }
 
 void orc_rng_floats(void* s, int n, float* out) {
     Scene& sc = *(Scene*)s;

@@ -75,6 +75,7 @@ SYMBOLS = {
     "rt_scene_set_camera": (_I, [_VP, _VP, _VP, _VP, _F, _F, _F, _F]),
     "rt_scene_get_camera": (_I, [_VP, _VP]),
     "rt_scene_set_background": (_I, [_VP, _F, _F, _F]),
+    "rt_scene_set_normal_mapping": (_I, [_VP, _I]),
     "rt_scene_flatten": (_I, [_VP, C.POINTER(FlatInfo)]),
     "rt_scene_get_flat": (_I, [_VP] + [_VP] * 10),
     "rt_scene_get_search_structure": (_I, [_VP, C.POINTER(_I), _VP, C.POINTER(_I), _VP]),
@@ -261,6 +262,9 @@ class Scene:
 
     def set_background(self, rgb):
         _check(lib.rt_scene_set_background(self.h, rgb[0], rgb[1], rgb[2]))
+
+    def set_normal_mapping(self, on):
+        _check(lib.rt_scene_set_normal_mapping(self.h, 1 if on else 0))
 
     def flatten(self):
         info = FlatInfo()

@@ -500,6 +500,33 @@ int Scene::buildBvh(Composite& c, std::vector<BoxedObj>& objs, size_t start, siz
 }
 
 // Threads the host-side builders may use: the machine's, at most 16 (RT_BUILD_THREADS overrides).
+bool tangentFrame(const float* pos, const float* uv, float* tangent, float* bitangent) {
+    for (int k = 0; k < 3; k++) tangent[k] = bitangent[k] = 0.0f;
+    if (uv[0] == -1.0f) return false;
+    const float du1 = uv[2] - uv[0], dv1 = uv[3] - uv[1], du2 = uv[4] - uv[0], dv2 = uv[5] - uv[1];
+    const float det = du1 * dv2 - du2 * dv1;
+    if (det == 0.0f || !std::isfinite(det)) return false;
+    const float f = 1.0f / det;
+    if (!std::isfinite(f)) return false;
+    bool any = false;
+    for (int k = 0; k < 3; k++) {
+        const float e1 = pos[3 + k] - pos[k], e2 = pos[6 + k] - pos[k];
+        tangent[k] = f * (dv2 * e1 - dv1 * e2);
+        bitangent[k] = f * (-du2 * e1 + du1 * e2);
+        any = any || tangent[k] != 0.0f;
+    }
+    bool anyB = false, finite = true;
+    for (int k = 0; k < 3; k++) {
+        anyB = anyB || bitangent[k] != 0.0f;
+        finite = finite && std::isfinite(tangent[k]) && std::isfinite(bitangent[k]);
+    }
+    if (!(any && anyB && finite)) {
+        for (int k = 0; k < 3; k++) tangent[k] = bitangent[k] = 0.0f;
+        return false;
+    }
+    return true;
+}
+
 unsigned buildThreads() {
     if (const char* e = std::getenv("RT_BUILD_THREADS")) return (unsigned)std::max(1, std::atoi(e));
     if (const char* e = std::getenv("OMP_NUM_THREADS")) return (unsigned)std::min(16, std::max(1, std::atoi(e)));

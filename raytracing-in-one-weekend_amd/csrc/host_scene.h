@@ -105,6 +105,12 @@ struct Camera22 {
 
 unsigned buildThreads();  // threads the host-side builders may use
 
+// Tangent and bitangent of a triangle from its positions (9 floats) and texture coordinates (6 floats):
+//   T = f (dv2 e1 - dv1 e2),  B = f (-du2 e1 + du1 e2),  f = 1 / (du1 dv2 - du2 dv1),
+// e_k = p_k - p_0, (du_k, dv_k) = uv_k - uv_0.  False (and zeros) when the triangle has no texture
+// coordinates (uv0.x == -1, the reference's marker) or its uv triangle is degenerate.
+bool tangentFrame(const float* pos9, const float* uv6, float* tangent3, float* bitangent3);
+
 class Scene {
 public:
     Scene();
@@ -152,6 +158,7 @@ public:
     std::vector<Obj> world;  // Scene::world.objects
     Camera22 camera{};
     float background[3] = {0, 0, 0};
+    bool normal_mapping = false;  // opt-in: PBR normal maps take effect (the reference computes the mapped normal and drops it)
     FlatScene flat;
 
 private:

@@ -417,6 +417,12 @@ int rt_scene_get_camera(const rt_scene* s, float* out22) {
     std::memcpy(out22, &s->sc.camera, sizeof(float) * 22);
     return RT_OK;
 }
+int rt_scene_set_normal_mapping(rt_scene* s, int on) {
+    if (!s) return fail(RT_ERR_INVALID, "null scene");
+    s->sc.normal_mapping = on != 0;
+    return RT_OK;
+}
+
 int rt_scene_set_background(rt_scene* s, float r, float g, float b) {
     if (!s) return fail(RT_ERR_INVALID, "null scene");
     s->sc.background[0] = r;
@@ -661,6 +667,20 @@ int rt_upload_scene(rt_context* ctx, rt_scene* s) {
         triS[4 * i + 3] = make_float4(t.uv[3], t.uv[4], t.uv[5], 0.f);
         triMat[i] = t.mat;
     }
+    // Tangent frame per triangle, for scenes with normal mapping switched on: the uv-delta construction of
+    // R/src/Core/Hittable.h:110-125 with each uv difference paired with the edge to the same vertex
+    // (the reference pairs them crosswise, one reason its mapped normal "doesn't work properly yet").
+    std::vector<float4> triF;
+    if (sc.normal_mapping) {
+        triF.resize(sc.triangles.size() * 2);
+        for (size_t i = 0; i < sc.triangles.size(); i++) {
+            const rt::HostTriangle& t = sc.triangles[i];
+            float tan[3], bit[3];
+            const bool ok = rt::tangentFrame(t.pos, t.uv, tan, bit);
+            triF[2 * i] = make_float4(tan[0], tan[1], tan[2], ok ? 1.0f : 0.0f);
+            triF[2 * i + 1] = make_float4(bit[0], bit[1], bit[2], 0.0f);
+        }
+    }
     std::vector<float4> mats(sc.materials.size() * 2);
     for (size_t i = 0; i < sc.materials.size(); i++) {
         const rt::HostMaterial& m = sc.materials[i];
@@ -721,6 +741,8 @@ int rt_upload_scene(rt_context* ctx, rt_scene* s) {
     if ((rc = devUpload(ctx, sphereMat, &d.sphere_mat))) return rc;
     if ((rc = devUpload(ctx, triI, &d.tri_isect))) return rc;
     if ((rc = devUpload(ctx, triS, &d.tri_shade))) return rc;
+    if ((rc = devUpload(ctx, triF, &d.tri_frame))) return rc;
+    d.normal_mapping = sc.normal_mapping ? 1 : 0;
     if ((rc = devUpload(ctx, triMat, &d.tri_mat))) return rc;
     if ((rc = devUpload(ctx, mats, &d.materials))) return rc;
     if ((rc = devUpload(ctx, texels, &d.texels))) return rc;

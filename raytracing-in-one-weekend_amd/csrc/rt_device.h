@@ -24,12 +24,14 @@ struct DevScene {
     const float4* tri_isect;  // 3 x float4 per triangle: {v0.xyz, -}, {edge1.xyz, -}, {edge2.xyz, -}
     const float4* tri_shade;  // 4 x float4: {n0.xyz, uv0.x}, {n1.xyz, uv0.y}, {n2.xyz, uv1.x}, {uv1.y, uv2.x, uv2.y, -}
     const int* tri_mat;
+    const float4* tri_frame;  // normal mapping only: 2 x float4 per triangle {tangent.xyz, 1 if usable}, {bitangent.xyz, -}
     const float4* materials;  // 2 x float4: {r, g, b, param}, {kind, texD, texR, texN} (ints bit-cast)
     const uint32_t* texels;   // all textures, RGBX8, one dword per texel
     const int4* tex_desc;     // {first texel, width, height, 0}
     const float* lut;         // 256-entry 8-bit -> float map
     int n_nodes, n_prim_refs, n_fast_nodes, n_fast_refs, n_spheres, n_tris, n_mats;
     int fast_oct_stride;      // > 0: fast_nodes holds 8 direction-ordered copies of this many entries each
+    int normal_mapping;       // 1: PBR materials with a normal map shade with the mapped normal (off: as the reference, the map is ignored)
     int force_ref;            // 1: always walk `nodes` in the reference's order (diagnostics)
     float origin_limit;       // rays starting further than this from the coordinate origin (any axis) walk `nodes`
     float cam[22];            // origin, lowerLeftCorner, horizontal, vertical, u, v, w, lensRadius

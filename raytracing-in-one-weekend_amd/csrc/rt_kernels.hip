@@ -369,6 +369,7 @@ struct Surface {
     bool front;
     float u, v;
     int mat;
+    int tri;  // triangle id, -1 for a sphere
 };
 
 // The HitRecord fields of the closest hit, computed once after traversal from (primitive, t):
@@ -404,6 +405,7 @@ __device__ __forceinline__ Surface surfaceAt(const DevScene& sc, const SceneView
             s.v = v;
         }
         s.mat = sv.tri_mat[id];
+        s.tri = (int)id;
     } else {
         const float4 sp = sv.spheres[id];
         V3 c{sp.x, sp.y, sp.z};
@@ -411,6 +413,7 @@ __device__ __forceinline__ Surface surfaceAt(const DevScene& sc, const SceneView
         s.front = dot(r.d, outward) < 0;
         s.n = s.front ? outward : -outward;
         s.mat = sv.sphere_mat[id];
+        s.tri = -1;
     }
     return s;
 }
@@ -427,6 +430,19 @@ __device__ __forceinline__ V3 textureAt(const DevScene& sc, int tex, float u, fl
     idx = idx < 0 ? 0 : (idx >= n ? n - 1 : idx);
     const uint32_t px = sc.texels[(size_t)d.x + (size_t)idx];
     return {sc.lut[px & 255u], sc.lut[(px >> 8) & 255u], sc.lut[(px >> 16) & 255u]};
+}
+
+// The same texel as plain byte / 255: a normal map holds directions, not colours, and must not go
+// through the gamma map of stbi_loadf (which is what the reference's Texture does to every file).
+__device__ __forceinline__ V3 textureAtLinear(const DevScene& sc, int tex, float u, float v) {
+    const int4 d = sc.tex_desc[tex];
+    int tx = (int)((u * d.y) - 0.5f);
+    int ty = (int)(((1 - v) * d.z) - 0.5f);
+    long long idx = (long long)ty * d.z + tx;
+    const long long n = (long long)d.y * d.z;
+    idx = idx < 0 ? 0 : (idx >= n ? n - 1 : idx);
+    const uint32_t px = sc.texels[(size_t)d.x + (size_t)idx];
+    return {(float)(px & 255u) / 255.0f, (float)((px >> 8) & 255u) / 255.0f, (float)((px >> 16) & 255u) / 255.0f};
 }
 
 // vecNearZero, R/src/Core/RTWeekend.cpp:39-43: every |component| < 1e-8, compared as doubles there.
@@ -510,19 +526,32 @@ __device__ __forceinline__ bool scatter(const DevScene& sc, const SceneView& sv,
         emit = {m0.x, m0.y, m0.z};
         return false;
     }
-    // PBRMaterial, Material.h:121-160.  The normal-map result is overwritten by rec.normal
-    // at :140, so only the diffuse and roughness maps influence the path.
+    // PBRMaterial, Material.h:121-160.  The reference forms the normal-mapped normal (:123-138) and then
+    // overwrites it with rec.normal (:140), so by default only the diffuse and roughness maps influence the
+    // path.  With normal mapping switched on for the scene the mapped normal is used instead:
+    // normalize(TBN * (2 texel - 1)) with the triangle's unit tangent and bitangent and the shading normal.
     if (COUNT) st->v[C_PBR]++;
-    const int texD = (int)fbits(m1.y), texR = (int)fbits(m1.z);
+    const int texD = (int)fbits(m1.y), texR = (int)fbits(m1.z), texN = (int)fbits(m1.w);
+    V3 nrm = s.n;
+    if (sc.normal_mapping && texN >= 0 && s.tri >= 0) {
+        const float4 f0 = sc.tri_frame[2 * s.tri], f1 = sc.tri_frame[2 * s.tri + 1];
+        if (f0.w != 0.0f) {
+            const V3 T = normalize(V3{f0.x, f0.y, f0.z}), B = normalize(V3{f1.x, f1.y, f1.z}), N = normalize(s.n);
+            const V3 c = textureAtLinear(sc, texN, s.u, s.v);
+            const V3 m{c.x * 2.0f - 1.0f, c.y * 2.0f - 1.0f, c.z * 2.0f - 1.0f};
+            nrm = normalize(V3{(T.x * m.x + B.x * m.y) + N.x * m.z, (T.y * m.x + B.y * m.y) + N.y * m.z,
+                               (T.z * m.x + B.z * m.y) + N.z * m.z});
+        }
+    }
     atten = textureAt(sc, texD, s.u, s.v);
     if (texR >= 0) {
-        V3 reflected = reflect(unitIn, s.n);
+        V3 reflected = reflect(unitIn, nrm);
         V3 rough = textureAt(sc, texR, s.u, s.v);
         out.d = reflected + rough * ball;
-        return dot(out.d, s.n) > 0;
+        return dot(out.d, nrm) > 0;
     }
-    V3 dir = s.n + normalize(ball);
-    if (nearZero(dir)) dir = s.n;
+    V3 dir = nrm + normalize(ball);
+    if (nearZero(dir)) dir = nrm;
     out.d = dir;
     return true;
 }
@@ -1262,6 +1291,7 @@ __global__ void scatterKernel(DevScene sc, int n, const int* mat, const float* r
     s.u = uv[2 * i];
     s.v = uv[2 * i + 1];
     s.mat = mat[i];
+    s.tri = -1;
     Rng rng;
     rng.init(key4[4 * i], key4[4 * i + 1], (int)key4[4 * i + 2]);
     rng.counter = key4[4 * i + 3];

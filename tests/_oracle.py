@@ -41,6 +41,7 @@ def lib():
         L.orc_set_camera.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_float] * 4
         L.orc_get_camera.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_set_background.argtypes = [C.c_void_p] + [C.c_float] * 3
+        L.orc_set_normal_mapping.argtypes = [C.c_void_p, C.c_int]
         L.orc_rng_floats.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         for name in ("orc_num_spheres", "orc_num_triangles", "orc_num_materials"):
             getattr(L, name).argtypes = [C.c_void_p]
@@ -134,6 +135,9 @@ class OracleScene:
 
     def set_background(self, rgb):
         self.L.orc_set_background(self.h, rgb[0], rgb[1], rgb[2])
+
+    def set_normal_mapping(self, on):
+        self.L.orc_set_normal_mapping(self.h, 1 if on else 0)
 
     def dump(self):
         ns, nt, nm = (self.L.orc_num_spheres(self.h), self.L.orc_num_triangles(self.h),
