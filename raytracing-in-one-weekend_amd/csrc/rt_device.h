@@ -31,6 +31,7 @@ struct DevScene {
     const float* lut;         // 256-entry 8-bit -> float map
     int n_nodes, n_prim_refs, n_fast_nodes, n_fast_refs, n_spheres, n_tris, n_mats;
     int fast_oct_stride;      // > 0: fast_nodes holds 8 direction-ordered copies of this many entries each
+    int has_pbr;              // 1: some material is a PBRMaterial
     int normal_mapping;       // 1: PBR materials with a normal map shade with the mapped normal (off: as the reference, the map is ignored)
     int force_ref;            // 1: always walk `nodes` in the reference's order (diagnostics)
     float origin_limit;       // rays starting further than this from the coordinate origin (any axis) walk `nodes`

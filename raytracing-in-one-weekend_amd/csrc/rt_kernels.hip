@@ -175,11 +175,12 @@ __device__ __forceinline__ bool slabPassFast(const float4& a, const float4& b, f
 // Sphere::Hit / Triangle::Hit (R/src/Core/Hittable.h:228-255, 58-141) for one leaf reference:
 // true with the hit distance (and a triangle's barycentrics) if the primitive is hit within
 // [0.001, tMax].  `tMax < t` rejects, equality accepts, as in the reference.
-template <bool COUNT>
+// FULL = false: the scene holds spheres only (the triangle branch is left out of the code).
+template <bool COUNT, bool FULL = true>
 __device__ __forceinline__ bool primRoot(const SceneView& sv, uint32_t ref, const Ray& r, float a, float tMax, float& tOut,
                                          float& uOut, float& vOut, Stats* st) {
     const uint32_t id = ref & kRefId;
-    if (ref & kRefTri) {
+    if (FULL && (ref & kRefTri)) {
         // edges are precomputed on the host with the reference's two subtractions
         if (COUNT) st->v[C_TRI]++;
         const float4 q0 = sv.tris[3 * id], q1 = sv.tris[3 * id + 1], q2 = sv.tris[3 * id + 2];
@@ -233,8 +234,9 @@ __device__ __forceinline__ void primRef(const SceneView& sv, uint32_t ref, const
     }
 }
 
+template <bool FULL = true>
 __device__ __forceinline__ int refOrder(const SceneView& sv, uint32_t ref) {
-    return (ref & kRefTri) ? sv.tri_ord[ref & kRefId] : sv.sphere_ord[ref & kRefId];
+    return (FULL && (ref & kRefTri)) ? sv.tri_ord[ref & kRefId] : sv.sphere_ord[ref & kRefId];
 }
 
 // Update rule for primitives that arrive in any order: smallest hit distance wins, and of two
@@ -324,10 +326,10 @@ __device__ __forceinline__ Hit traverseFast(const SceneView& sv, int n_nodes, co
 // The condition under which the reference's walk returns exactly the hit found by the search
 // structure: the innermost reference box above the winner, and every enclosing box that does
 // not contain it, pass the reference's slab test with tMax = the winner's distance.
-template <bool COUNT>
+template <bool COUNT, bool FULL = true>
 __device__ __forceinline__ bool guardsPass(const SceneView& sv, const Ray& r, float invx, float invy, float invz, const Hit& h,
                                            Stats* st) {
-    int g = sv.prim_guard[refOrder(sv, h.ref)];
+    int g = sv.prim_guard[refOrder<FULL>(sv, h.ref)];
     while (g >= 0) {
         if (COUNT) st->v[C_NODE]++;
         if (!slabPass(sv.nodes[2 * g], sv.nodes[2 * g + 1], r, invx, invy, invz, h.t)) return false;
@@ -374,6 +376,7 @@ struct Surface {
 
 // The HitRecord fields of the closest hit, computed once after traversal from (primitive, t):
 // same expressions as Sphere::Hit (Hittable.h:248-252) and Triangle::Hit (Hittable.h:86-107).
+template <bool FULL = true>
 __device__ __forceinline__ Surface surfaceAt(const DevScene& sc, const SceneView& sv, const Ray& r, const Hit& h) {
     Surface s;
     s.p = r.o + h.t * r.d;
@@ -381,7 +384,7 @@ __device__ __forceinline__ Surface surfaceAt(const DevScene& sc, const SceneView
     s.v = 0.0f;
     s.front = false;
     const uint32_t id = h.ref & kRefId;
-    if (h.ref & kRefTri) {
+    if (FULL && (h.ref & kRefTri)) {
         const float4 q1 = sv.tris[3 * id + 1], q2 = sv.tris[3 * id + 2];
         const float4 a0 = sc.tri_shade[4 * id], a1 = sc.tri_shade[4 * id + 1], a2 = sc.tri_shade[4 * id + 2],
                      a3 = sc.tri_shade[4 * id + 3];
@@ -472,7 +475,8 @@ __device__ __forceinline__ float reflectance(float cosine, float refIdx) {
 
 // Material::scatter for the five material kinds (R/src/Material/Material.h:22-160).
 // Returns true if the path continues with `out` and `atten`; false ends it with `emit`.
-template <bool COUNT>
+// FULL = false: no material of the scene is a PBRMaterial (texture code left out).
+template <bool COUNT, bool FULL = true>
 __device__ __forceinline__ bool scatter(const DevScene& sc, const SceneView& sv, const Ray& in, const Surface& s,
                                         Rng& rng, Ray& out, V3& atten, V3& emit, Stats* st) {
     const float4 m0 = sv.materials[2 * s.mat], m1 = sv.materials[2 * s.mat + 1];
@@ -482,10 +486,10 @@ __device__ __forceinline__ bool scatter(const DevScene& sc, const SceneView& sv,
     // Lambertian, Metal and PBR each draw exactly one point in the unit sphere and nothing before
     // it, so the rejection loop runs once for all the lanes of a wave, whatever their material.
     V3 ball{0.0f, 0.0f, 0.0f};
-    if (kind == 0 || kind == 1 || kind == 4) ball = randomInUnitSphere(rng);
+    if (kind == 0 || kind == 1 || (FULL && kind == 4)) ball = randomInUnitSphere(rng);
     // likewise glm::normalize(rayIn.direction) of Metal, Dielectric and PBR
     V3 unitIn{0.0f, 0.0f, 0.0f};
-    if (kind == 1 || kind == 2 || kind == 4) unitIn = normalize(in.d);
+    if (kind == 1 || kind == 2 || (FULL && kind == 4)) unitIn = normalize(in.d);
     if (kind == 0) {  // Lambertian, Material.h:22-36
         if (COUNT) st->v[C_LAMB]++;
         V3 dir = s.n + normalize(ball);
@@ -521,7 +525,7 @@ __device__ __forceinline__ bool scatter(const DevScene& sc, const SceneView& sv,
         }
         return true;
     }
-    if (kind == 3) {  // DiffuseLight, Material.h:103-110
+    if (kind == 3 || !FULL) {  // DiffuseLight, Material.h:103-110
         if (COUNT) st->v[C_LIGHT]++;
         emit = {m0.x, m0.y, m0.z};
         return false;
@@ -797,7 +801,7 @@ __device__ __forceinline__ int popc64(unsigned long long m) {
 // TIME (diagnostic): instead of path counters, each wave adds up its clock ticks per operation
 // -- box bursts, primitive runs, SHADE, NEWPATH, reference-order box steps, and everything else
 // (votes, loop overhead) -- into the scheduling-statistics slots.
-template <bool LDS, bool COUNT, bool TIME = false>
+template <bool LDS, bool COUNT, bool TIME = false, bool FULL = true>
 __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
     const DevScene& sc = a.sc;
     fillCounterLut();
@@ -1030,18 +1034,20 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
                             // the reference-order walk tests against the running closest distance and takes
                             // every hit; the search-structure walk tests without a limit and orders the hits.
                             float t, u = mode ? h.bu : 0.0f, v = mode ? h.bv : 0.0f;
-                            if (primRoot<COUNT>(sv, ref, r, aa, mode ? h.t : __builtin_inff(), t, u, v, &st)) {
+                            if (primRoot<COUNT, FULL>(sv, ref, r, aa, mode ? h.t : __builtin_inff(), t, u, v, &st)) {
                                 bool take = true;
                                 if (!mode) {
                                     bad = t != t;
                                     take = !bad && (h.ref == kNoHit || t < h.t ||
-                                                    (t == h.t && refOrder(sv, ref) > refOrder(sv, h.ref)));
+                                                    (t == h.t && refOrder<FULL>(sv, ref) > refOrder<FULL>(sv, h.ref)));
                                 }
                                 if (take) {
                                     h.t = t;
                                     h.ref = ref & ~kRefLast;
-                                    h.bu = u;
-                                    h.bv = v;
+                                    if (FULL) {
+                                        h.bu = u;
+                                        h.bv = v;
+                                    }
                                 }
                             }
                             if (bad) {
@@ -1104,17 +1110,17 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
             lap(T_REFBOX);
         } else if (chosen == OP_SHADE) {
             if (op == OP_SHADE) {
-                const bool vouched = mode != 0 || guardsPass<COUNT>(sv, r, invx, invy, invz, h, &st);
+                const bool vouched = mode != 0 || guardsPass<COUNT, FULL>(sv, r, invx, invy, invz, h, &st);
                 lap(T_GUARD);
                 if (!vouched) {
                     retraceInReferenceOrder();
                 } else {
                     if (COUNT) st.v[C_HITS]++;
-                    Surface sf = surfaceAt(sc, sv, r, h);
+                    Surface sf = surfaceAt<FULL>(sc, sv, r, h);
                     lap(T_SURFACE);
                     Ray out;
                     V3 atten, emit;
-                    const bool alive = scatter<COUNT>(sc, sv, r, sf, rng, out, atten, emit, &st);
+                    const bool alive = scatter<COUNT, FULL>(sc, sv, r, sf, rng, out, atten, emit, &st);
                     lap(T_SCATTER);
                     if (!alive) {
                         endPath(emit);
@@ -1352,13 +1358,13 @@ __global__ void __launch_bounds__(256) resolveKernel(const float4* payloads, siz
 }
 
 // ------------------------------------------------------------------ launch wrappers
-template <bool LDS, bool COUNT, bool TIME = false>
+template <bool LDS, bool COUNT, bool TIME = false, bool FULL = true>
 static hipError_t launchWavefrontT(const RenderArgs& a, int blocks, int threads, size_t shmem, hipStream_t stream) {
     (void)hipGetLastError();  // an earlier, unrelated failure must not be reported as this launch's
     if (LDS)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(renderWavefront<LDS, COUNT, TIME>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(renderWavefront<LDS, COUNT, TIME, FULL>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    renderWavefront<LDS, COUNT, TIME><<<blocks, threads, shmem, stream>>>(a);
+    renderWavefront<LDS, COUNT, TIME, FULL><<<blocks, threads, shmem, stream>>>(a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const int nSlots = a.n_local_tiles * 64;
@@ -1372,6 +1378,12 @@ hipError_t launchWavefront(const RenderArgs& a, bool lds, bool count, int blocks
     if (count && a.timing)
         return lds ? launchWavefrontT<true, false, true>(a, blocks, threads, shmem, stream)
                    : launchWavefrontT<false, false, true>(a, blocks, threads, 0, stream);
+    // scenes of spheres without PBR materials run a build of the loop that leaves the triangle and texture
+    // code out (fewer registers held by every lane through every operation)
+    const bool plain = a.sc.n_tris == 0 && !a.sc.has_pbr;
+    if (!count && plain)
+        return lds ? launchWavefrontT<true, false, false, false>(a, blocks, threads, shmem, stream)
+                   : launchWavefrontT<false, false, false, false>(a, blocks, threads, 0, stream);
     if (lds) return count ? launchWavefrontT<true, true>(a, blocks, threads, shmem, stream)
                           : launchWavefrontT<true, false>(a, blocks, threads, shmem, stream);
     return count ? launchWavefrontT<false, true>(a, blocks, threads, 0, stream)
