@@ -1198,6 +1198,40 @@ void orc_write_color(int n, const float* sums3, int samplesPerPixel, uint8_t* rg
 // order 0: recursive estimator (reference evaluation order); 1: front-to-back throughput order.
 // accumRGBA (W*H*4 floats, row j at offset j*W, row 0 = bottom) receives the float sums
 // (alpha = sample count); rgba8 the writeColor bytes.  Rows [row0, row1) only.
+// The rays of one hash-stream path (pixel, sample), one after the other, and what each of them hit:
+// rays6[k] = origin, direction; hits[k] = {primitive kind (-1 none, 0 sphere, 1 triangle), id}; t[k].
+// Returns the number of rays.  For narrowing down a difference between two renderers to one ray.
+int orc_path_rays(void* s, int W, int H, int px, int py, int sample, int maxDepth, int maxRays, float* rays6, int* hits2,
+                  float* t) {
+    const Scene& sc = *(Scene*)s;
+    Rng rng;
+    rng.mode = Rng::HASH;
+    rng.px = (uint32_t)px;
+    rng.py = (uint32_t)py;
+    rng.sample = sample;
+    rng.counter = 0;
+    float u = (px + rng.randomFloat()) / (W - 1);
+    float v = (py + rng.randomFloat()) / (H - 1);
+    Ray r = sc.camera.GetRay(u, v, rng);
+    int n = 0;
+    for (int depth = maxDepth; depth > 0 && n < maxRays; depth--) {
+        HitRecord rec;
+        const bool hit = sc.world.Hit(r, 0.001f, kInfinity, rec, rng);
+        rays6[6 * n] = r.origin.x; rays6[6 * n + 1] = r.origin.y; rays6[6 * n + 2] = r.origin.z;
+        rays6[6 * n + 3] = r.direction.x; rays6[6 * n + 4] = r.direction.y; rays6[6 * n + 5] = r.direction.z;
+        hits2[2 * n] = hit ? rec.primKind : -1;
+        hits2[2 * n + 1] = hit ? rec.primId : -1;
+        t[n] = hit ? rec.t : kInfinity;
+        n++;
+        if (!hit) break;
+        Ray scattered;
+        vec3 attenuation;
+        if (!rec.mat->scatter(r, rec, attenuation, scattered, rng)) break;
+        r = scattered;
+    }
+    return n;
+}
+
 void orc_render(void* s, int W, int H, int firstSample, int nSamples, int maxDepth, int rngMode, int order, int threads,
                 int row0, int row1, float* accumRGBA, uint8_t* rgba8, OrcCounters* countersOut) {
     Scene& sc = *(Scene*)s;

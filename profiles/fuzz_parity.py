@@ -1,5 +1,5 @@
 """Randomised parity run: many small random worlds (spheres of all four materials, loose triangles,
-lathe meshes with smooth or flat normals and PBR or Lambertian materials, lights), random cameras
+lathe meshes with smooth or flat normals and PBR (a third of them normal-mapped) or Lambertian materials, lights), random cameras
 (inside and outside the world, with and without a lens), with and without the reference's top-level
 BVH; every accumulation image of the GPU path must equal the CPU oracle's bit for bit.
 
@@ -59,6 +59,7 @@ def make_builder(seed):
     vfov = float(rr.choice([20.0, 40.0, 90.0]))
     bg = tuple(float(x) for x in rr.choice([0.0, 0.7, 1.0], 3))
     tex_seed = int(rr.randint(1 << 20))
+    normal_maps = seed % 3 == 0   # PBR meshes carry a normal map, and the scene's switch is on
 
     def build(s):
         mats = []
@@ -75,7 +76,8 @@ def make_builder(seed):
             if pbr:
                 td = s.add_texture(scenes.noise_texture(16, tex_seed + k))
                 tr = s.add_texture(scenes.noise_texture(16, tex_seed + 100 + k)) if rough else -1
-                mat = s.add_pbr(td, tr, -1)
+                tn = s.add_texture(scenes.noise_texture(24, tex_seed + 200 + k)) if normal_maps else -1
+                mat = s.add_pbr(td, tr, tn)
             else:
                 mat = mats[k % len(mats)]
             s.add_mesh(model, m["positions"], m["indices"], mat, normals=m["normals"] if smooth else None,
@@ -84,6 +86,7 @@ def make_builder(seed):
             s.wrap_bvh()
         s.set_camera(lookfrom, lookat, (0.0, 1.0, 0.0), vfov, 1.0, aperture, float(max(1e-3, np.linalg.norm(lookat - lookfrom))))
         s.set_background(bg)
+        s.set_normal_mapping(normal_maps)
 
     return build
 

@@ -44,6 +44,7 @@ struct BuildArgs {
     const float4* spheres;      // {c.xyz, r}
     const float4* tris;         // 3 x float4: v0, v1 - v0, v2 - v0
     float pad_floor;
+    float far_typical;  // distance between ray origin and primitive for which the boxes are padded (see fast_bvh.cpp)
     float cmin[3], cinv[3];     // centre bounds: (c - cmin) * cinv in [0, 1]
     float4* pbox;               // 2 per primitive, input order: {min.xyz, -}, {max.xyz, -}
     uint64_t* keys;
@@ -78,7 +79,11 @@ __device__ __forceinline__ void paddedBox(const BuildArgs& a, int i, float mn[3]
     }
     // (the host pads by max(own, min(floor, size / 10)); the edges are re-derived here from v0 + edge,
     // which may differ from the stored vertex in the last bit -- 1e3 times less than the padding)
-    const float d = fmaxf(2e-4f * m + 1e-4f, fminf(a.pad_floor, 0.1f * size)) * 1.001f;
+    // plus what the primitive's own hit test can be off by at the distance the scene's rays normally start from
+    const float D = a.far_typical;
+    const float rr = (ref & kTri) ? 0.0f : 0.5f * size;
+    const float far = (ref & kTri) ? (64.0f / 16777216.0f) * D : sqrtf(rr * rr + (32.0f / 16777216.0f) * D * D) - rr;
+    const float d = fmaxf(2e-4f * m + 1e-4f, fminf(a.pad_floor, 0.1f * size)) * 1.001f + far * 1.02f;
     for (int k = 0; k < 3; k++) {
         mn[k] -= d;
         mx[k] += d;
@@ -298,7 +303,7 @@ __global__ void __launch_bounds__(256) emitEntries(EmitArgs e) {
 // want_copies(entries of one copy) decides whether the eight direction-ordered copies are written; *stride
 // comes back 0 (one copy) or entries + 1.
 hipError_t buildSearchStructureOnDevice(int n, const uint32_t* d_refs, const float4* d_spheres, const float4* d_tris,
-                                        float pad_floor, const float cmin[3], const float cmax[3], hipStream_t stream,
+                                        float pad_floor, float far_typical, const float cmin[3], const float cmax[3], hipStream_t stream,
                                         const std::function<bool(int)>& want_copies, float4** entries, uint32_t** out_refs,
                                         int* n_entries, int* stride, float* build_ms) {
     *stride = 0;
@@ -353,6 +358,7 @@ hipError_t buildSearchStructureOnDevice(int n, const uint32_t* d_refs, const flo
         a.spheres = d_spheres;
         a.tris = d_tris;
         a.pad_floor = pad_floor;
+        a.far_typical = far_typical;
         for (int k = 0; k < 3; k++) {
             a.cmin[k] = cmin[k];
             const float ext = cmax[k] - cmin[k];

@@ -23,6 +23,7 @@
 // component is zero (infinite reciprocal, where the NaN-skipping of the slab test breaks the
 // monotonicity argument).
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -414,46 +415,110 @@ void Scene::buildFastStructure() {
         if (f.tri_ord[i] >= 0)
             for (int k = 0; k < 9; k++) extent = std::max(extent, std::fabs(triangles[i].pos[k]));
     const float originFloor = extent * (1.01f / 2097152.0f);
+    // The padding of a primitive box has two parts.  `base`: the rounding of the fused box test (above).
+    // `far`: the inaccuracy of the reference's own hit test, which grows with the distance D between ray origin
+    // and primitive (FlatScene::far_*): it is budgeted for the distance D_typ within which this scene's rays
+    // normally start -- the eye and the scene's own primitives -- and rays that start further away widen the
+    // boxes themselves by the difference (farRayPad() in the kernels).
+    const double kSphereErr = 32.0 / 16777216.0, kTriErr = 64.0 / 16777216.0;
+    auto phantomSphere = [&](double r, double D) { return std::sqrt(r * r + kSphereErr * D * D) - r; };
     float minPad = std::numeric_limits<float>::infinity();
-    auto pad = [&minPad, originFloor, &f](PrimBox& b) {
+    auto primBox = [&](bool tri, size_t i) {
+        PrimBox b;
+        if (tri) {
+            for (int k = 0; k < 3; k++) {
+                const float a = triangles[i].pos[k], c = triangles[i].pos[3 + k], d = triangles[i].pos[6 + k];
+                b.mn[k] = std::min(a, std::min(c, d));
+                b.mx[k] = std::max(a, std::max(c, d));
+            }
+            b.ref = (uint32_t)i | kRefTriangle;
+        } else {
+            for (int k = 0; k < 3; k++) {
+                b.mn[k] = spheres[i].c[k] - std::fabs(spheres[i].r);
+                b.mx[k] = spheres[i].c[k] + std::fabs(spheres[i].r);
+            }
+            b.ref = (uint32_t)i;
+        }
+        return b;
+    };
+    auto basePad = [&](const PrimBox& b) {
         float m = 0.0f, size = 0.0f;
+        for (int k = 0; k < 3; k++) {
+            m = std::max(m, std::max(std::fabs(b.mn[k]), std::fabs(b.mx[k])));
+            size = std::max(size, b.mx[k] - b.mn[k]);
+        }
+        return std::max(2e-4f * m + 1e-4f, std::min(originFloor, 0.1f * size));
+    };
+    // pass 1: base paddings, the smallest of them, and the primitives whose base padding does not also cover
+    // their own test's inaccuracy at every distance a ray of this scene can start from
+    std::vector<std::pair<bool, size_t>> world;  // (triangle?, id) in the order of world_refs
+    for (size_t i = 0; i < spheres.size(); i++)
+        if (f.sphere_ord[i] >= 0) world.push_back({false, i});
+    for (size_t i = 0; i < triangles.size(); i++)
+        if (f.tri_ord[i] >= 0) world.push_back({true, i});
+    std::vector<float> base(world.size());
+    for (size_t w = 0; w < world.size(); w++) {
+        base[w] = basePad(primBox(world[w].first, world[w].second));
+        minPad = std::min(minPad, base[w]);
+    }
+    f.far_spheres = f.far_tris = 0;
+    f.far_rmin = 0.0f;
+    double farC[3] = {0, 0, 0}, farR = 0.0, rmin = std::numeric_limits<double>::infinity();
+    {
+        // the farthest a ray that uses the search structure can start from a primitive: origins are limited
+        // to minPad * 2^21 per axis (fastTestUsable), primitives to `extent`
+        const double reach = 1.7320508 * ((double)minPad * 2097152.0 + (double)extent) * 1.01;
+        std::vector<std::array<double, 3>> pts;
+        for (size_t w = 0; w < world.size(); w++) {
+            const size_t i = world[w].second;
+            if (!world[w].first) {
+                const double r = std::fabs((double)spheres[i].r);
+                if (phantomSphere(r, reach) <= 0.5 * base[w]) continue;  // covered at any distance
+                f.far_spheres++;
+                rmin = std::min(rmin, r);
+                pts.push_back({spheres[i].c[0], spheres[i].c[1], spheres[i].c[2]});
+            } else {
+                if (kTriErr * reach <= 0.5 * base[w]) continue;
+                f.far_tris++;
+                for (int v = 0; v < 3; v++)
+                    pts.push_back({triangles[i].pos[3 * v], triangles[i].pos[3 * v + 1], triangles[i].pos[3 * v + 2]});
+            }
+        }
+        for (const auto& q : pts)
+            for (int k = 0; k < 3; k++) farC[k] += q[k];
+        if (!pts.empty()) {
+            for (int k = 0; k < 3; k++) farC[k] /= (double)pts.size();
+            for (const auto& q : pts) {
+                double d2 = 0;
+                for (int k = 0; k < 3; k++) d2 += (q[k] - farC[k]) * (q[k] - farC[k]);
+                farR = std::max(farR, std::sqrt(d2));
+            }
+        }
+    }
+    // the distance budgeted for: from the eye to the far side of those primitives, or across them
+    double eyeDist2 = 0;
+    for (int k = 0; k < 3; k++) eyeDist2 += ((double)camera.origin[k] - farC[k]) * ((double)camera.origin[k] - farC[k]);
+    const bool anyFar = f.far_spheres + f.far_tris > 0;
+    const double dTyp = anyFar ? std::max(2.0 * farR, std::sqrt(eyeDist2) + farR) * 1.05 + 1e-3 : 0.0;
+    for (int k = 0; k < 3; k++) f.far_center[k] = (float)farC[k];
+    f.far_radius = (float)(farR * 1.001 + 1e-6);
+    f.far_rmin = f.far_spheres ? (float)rmin : 0.0f;
+    f.far_typical = (float)dTyp;
+    // pass 2: the padded boxes
+    for (size_t w = 0; w < world.size(); w++) {
+        PrimBox b = primBox(world[w].first, world[w].second);
         f.world_refs.push_back(b.ref);
         for (int k = 0; k < 3; k++) {
             const float c = 0.5f * (b.mn[k] + b.mx[k]);
             f.centroid_min[k] = std::min(f.centroid_min[k], c);
             f.centroid_max[k] = std::max(f.centroid_max[k], c);
-            m = std::max(m, std::max(std::fabs(b.mn[k]), std::fabs(b.mx[k])));
-            size = std::max(size, b.mx[k] - b.mn[k]);
         }
-        const float own = 2e-4f * m + 1e-4f;
-        const float d = std::max(own, std::min(originFloor, 0.1f * size));
-        minPad = std::min(minPad, d);
+        const double far = world[w].first ? kTriErr * dTyp : phantomSphere(std::fabs((double)spheres[world[w].second].r), dTyp);
+        const float d = (float)((double)base[w] + far * 1.01);
         for (int k = 0; k < 3; k++) {
             b.mn[k] -= d;
             b.mx[k] += d;
         }
-    };
-    for (size_t i = 0; i < spheres.size(); i++) {
-        if (f.sphere_ord[i] < 0) continue;  // not in the world
-        PrimBox b;
-        for (int k = 0; k < 3; k++) {
-            b.mn[k] = spheres[i].c[k] - std::fabs(spheres[i].r);
-            b.mx[k] = spheres[i].c[k] + std::fabs(spheres[i].r);
-        }
-        b.ref = (uint32_t)i;
-        pad(b);
-        if (!deferred) prims.push_back(b);
-    }
-    for (size_t i = 0; i < triangles.size(); i++) {
-        if (f.tri_ord[i] < 0) continue;
-        PrimBox b;
-        for (int k = 0; k < 3; k++) {
-            const float a = triangles[i].pos[k], c = triangles[i].pos[3 + k], d = triangles[i].pos[6 + k];
-            b.mn[k] = std::min(a, std::min(c, d));
-            b.mx[k] = std::max(a, std::max(c, d));
-        }
-        b.ref = (uint32_t)i | kRefTriangle;
-        pad(b);
         if (!deferred) prims.push_back(b);
     }
     f.fast_min_pad = minPad;

@@ -79,6 +79,18 @@ struct FlatScene {
     // subtraction), so rays that start further than fast_min_pad * 2^21 from the coordinate origin
     // are not vouched for by the padding and walk the reference-order array instead.
     float fast_min_pad = 0.0f;
+    // The primitive tests themselves lose accuracy with the distance D between ray origin and primitive:
+    // Sphere::Hit forms halfB^2 - a c from terms of size D^2, so its discriminant is off by up to about
+    // 32 * 2^-24 * D^2 and it reports "hits" for rays that pass a sphere of radius r at up to
+    // sqrt(r^2 + 32 * 2^-24 * D^2) from its centre; Triangle::Hit's barycentrics are off by about
+    // 64 * 2^-24 * D in position terms.  The reference returns those hits, so the search structure must not
+    // cull them.  Every box is padded for the distance far_typical within which the scene's rays normally
+    // start (from the eye, or from one primitive to another); a ray that starts further from the
+    // primitives concerned (far_spheres / far_tris of them: those the rounding part of the padding does not
+    // cover at any distance anyway; far_center / far_radius bound them, far_rmin is the smallest radius)
+    // widens every box by the difference (farRayPad() in the kernels).
+    int far_spheres = 0, far_tris = 0;
+    float far_center[3] = {0, 0, 0}, far_radius = 0.0f, far_rmin = 0.0f, far_typical = 0.0f;
     // Inputs of a device-side build of the search structure (csrc/device_bvh.hip): the primitives that
     // are in the world (leaf references without the last-of-run bit), the floor of the box padding,
     // and the bounds of the padded boxes' centres.  With defer_search_build set, flatten() prepares

@@ -27,7 +27,7 @@ hipError_t launchScatter(const DevScene& sc, int n, const int* mat, const float*
                          const int* front, const float* uv, const unsigned int* key4, float* atten, float* rayOut,
                          int* alive, unsigned int* counterOut, hipStream_t stream);
 hipError_t buildSearchStructureOnDevice(int n, const uint32_t* d_refs, const float4* d_spheres, const float4* d_tris,
-                                        float pad_floor, const float cmin[3], const float cmax[3], hipStream_t stream,
+                                        float pad_floor, float far_typical, const float cmin[3], const float cmax[3], hipStream_t stream,
                                         const std::function<bool(int)>& want_copies, float4** entries, uint32_t** out_refs,
                                         int* n_entries, int* stride, float* build_ms);
 hipError_t launchReflectance(int n, const float* cosine, const float* refIdx, float* out, hipStream_t stream);
@@ -774,7 +774,7 @@ int rt_upload_scene(rt_context* ctx, rt_scene* s) {
             return !fitsLds && nE <= (1 << 21) && envInt("RT_OCTANTS", 1) != 0;
         };
         HIP_TRY(rt::buildSearchStructureOnDevice((int)sc.flat.world_refs.size(), dWorld, d.spheres, d.tri_isect,
-                                                 sc.flat.pad_floor, sc.flat.centroid_min, sc.flat.centroid_max, ctx->stream,
+                                                 sc.flat.pad_floor, sc.flat.far_typical, sc.flat.centroid_min, sc.flat.centroid_max, ctx->stream,
                                                  wantCopies, &entries, &refs, &nEntries, &stride, &ctx->build_ms));
         ctx->scene_allocs.push_back(entries);
         ctx->scene_allocs.push_back(refs);
@@ -786,6 +786,12 @@ int rt_upload_scene(rt_context* ctx, rt_scene* s) {
     }
     d.force_ref = (ctx->force_ref || hugeCoords) ? 1 : 0;
     d.origin_limit = sc.flat.fast_min_pad * 2097152.0f;  // 2^21, see buildFastStructure()
+    d.far_spheres = sc.flat.far_spheres;
+    d.far_tris = sc.flat.far_tris;
+    for (int k = 0; k < 3; k++) d.far_center[k] = sc.flat.far_center[k];
+    d.far_radius = sc.flat.far_radius;
+    d.far_rmin = sc.flat.far_rmin;
+    d.far_typical = sc.flat.far_typical;
     ctx->huge_coords = hugeCoords;
     d.n_spheres = (int)sc.spheres.size();
     d.n_tris = (int)sc.triangles.size();

@@ -34,6 +34,11 @@ struct DevScene {
     int has_pbr;              // 1: some material is a PBRMaterial
     int normal_mapping;       // 1: PBR materials with a normal map shade with the mapped normal (off: as the reference, the map is ignored)
     int force_ref;            // 1: always walk `nodes` in the reference's order (diagnostics)
+    // per-ray widening of the search structure's boxes for rays that start far from small primitives
+    // (the reference's own hit tests lose accuracy with that distance and report hits the fixed padding
+    // does not cover; FlatScene::far_* on the host, farRayPad() in the kernels)
+    int far_spheres, far_tris;
+    float far_center[3], far_radius, far_rmin, far_typical;
     float origin_limit;       // rays starting further than this from the coordinate origin (any axis) walk `nodes`
     float cam[22];            // origin, lowerLeftCorner, horizontal, vertical, u, v, w, lensRadius
     float bg[3];

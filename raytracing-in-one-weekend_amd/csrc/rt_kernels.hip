@@ -162,14 +162,43 @@ struct __attribute__((aligned(4))) f32x2u {  // two floats at a 4-byte aligned a
 // per plane (two planes per packed instruction; the entry stores {min, max} pairs per axis), and
 // min/max instead of compare-and-swap.  Rays with a zero or denormal direction component never
 // get here (they walk the reference-order array).
+// `slack`: the ray's own widening of every box in units of distance along the ray (boxSlack): the test passes
+// when entry and exit distance are no further apart than that.
+template <bool WIDE = true>
 __device__ __forceinline__ bool slabPassFast(const float4& a, const float4& b, float invx, float invy, float invz,
-                                             float nox, float noy, float noz, float closest) {
+                                             float nox, float noy, float noz, float closest, float slack) {
     const f32x2 tx = __builtin_elementwise_fma(f32x2{a.x, a.y}, f32x2{invx, invx}, f32x2{nox, nox});
     const f32x2 ty = __builtin_elementwise_fma(f32x2{a.z, a.w}, f32x2{invy, invy}, f32x2{noy, noy});
     const f32x2 tz = __builtin_elementwise_fma(f32x2{b.x, b.y}, f32x2{invz, invz}, f32x2{noz, noz});
     const float tn = fmaxf(fmaxf(fminf(tx.x, tx.y), fminf(ty.x, ty.y)), fmaxf(fminf(tz.x, tz.y), kTMin));
     const float tf = fminf(fminf(fmaxf(tx.x, tx.y), fmaxf(ty.x, ty.y)), fminf(fmaxf(tz.x, tz.y), closest));
-    return tn <= tf;
+    return WIDE ? tn <= tf + slack : tn <= tf;
+}
+// A box widened by e on every side is entered at most e * |1/d| earlier and left at most e * |1/d| later on
+// each axis; with the largest of the three factors for all axes the widened test is implied by
+// "entry <= exit + 2 e max|1/d|" (the clamps to tMin and to the closest hit only make that easier to meet).
+__device__ __forceinline__ float boxSlack(float epad, float invx, float invy, float invz) {
+    return 2.0f * epad * fmaxf(fmaxf(fabsf(invx), fabsf(invy)), fabsf(invz));
+}
+
+// By how much a ray that starts at `o` widens every box of the search structure.  Sphere::Hit and
+// Triangle::Hit (R/src/Core/Hittable.h:228-255, 58-141) lose accuracy with the distance D between ray
+// origin and primitive: the sphere's discriminant is a difference of terms of size D^2, so a ray that
+// passes a sphere of radius r at up to sqrt(r^2 + 32 * 2^-24 * D^2) from its centre can still be given a
+// hit, and the reference returns it; a triangle's barycentrics are off by about 64 * 2^-24 * D.  The
+// boxes are padded for D = far_typical (the eye and the scene's own primitives are within that); a ray
+// that starts further from the primitives concerned (bounded by far_center / far_radius; far_rmin = the
+// smallest radius, which needs most) adds the difference.  Zero nearly always.
+__device__ __forceinline__ float farRayPad(const DevScene& sc, const V3& o) {
+    if ((sc.far_spheres | sc.far_tris) == 0) return 0.0f;
+    const float dx = o.x - sc.far_center[0], dy = o.y - sc.far_center[1], dz = o.z - sc.far_center[2];
+    const float D = (sqrtf(dx * dx + dy * dy + dz * dz) + sc.far_radius) * 1.0001f;
+    if (!(D > sc.far_typical)) return 0.0f;  // also for an origin that is not finite: such rays take the other walk
+    const float kS = 32.0f / 16777216.0f, kT = 64.0f / 16777216.0f, r = sc.far_rmin, T = sc.far_typical;
+    float e = 0.0f;
+    if (sc.far_spheres) e = sqrtf(r * r + kS * D * D) - sqrtf(r * r + kS * T * T);
+    if (sc.far_tris) e = fmaxf(e, kT * (D - T));
+    return e * 1.02f + 1e-7f;
 }
 
 // Sphere::Hit / Triangle::Hit (R/src/Core/Hittable.h:228-255, 58-141) for one leaf reference:
@@ -298,15 +327,16 @@ __device__ __forceinline__ Hit traverseRef(const SceneView& sv, int n_nodes, con
 // order-independent update.
 template <bool COUNT>
 __device__ __forceinline__ Hit traverseFast(const SceneView& sv, int n_nodes, const Ray& r, float invx, float invy, float invz,
-                                            float a, bool& bad, Stats* st) {
+                                            float a, float epad, bool& bad, Stats* st) {
     Hit h{__builtin_inff(), kNoHit, 0.0f, 0.0f};
     const float nox = -(r.o.x * invx), noy = -(r.o.y * invy), noz = -(r.o.z * invz);
+    const float slack = boxSlack(epad, invx, invy, invz);
     int idx = 0;
     while (idx < n_nodes) {
         const float4 n0 = sv.fnodes[2 * idx], n1 = sv.fnodes[2 * idx + 1];
         const int first = (int)fbits(n1.w);
         if (COUNT) st->v[C_NODE]++;
-        if (slabPassFast(n0, n1, invx, invy, invz, nox, noy, noz, h.t)) {
+        if (slabPassFast(n0, n1, invx, invy, invz, nox, noy, noz, h.t, slack)) {
             if (first >= 0) {
                 int p = first;
                 uint32_t ref;
@@ -359,7 +389,7 @@ __device__ __forceinline__ Hit closestHit(const DevScene& sc, const SceneView& s
     if (!sc.force_ref &&
         fastTestUsable(r.o, sc.origin_limit, invx, invy, invz, -(r.o.x * invx), -(r.o.y * invy), -(r.o.z * invz))) {
         bool bad = false;
-        Hit h = traverseFast<COUNT>(sv, sc.n_fast_nodes, r, invx, invy, invz, a, bad, st);
+        Hit h = traverseFast<COUNT>(sv, sc.n_fast_nodes, r, invx, invy, invz, a, farRayPad(sc, r.o), bad, st);
         if (!bad && (h.ref == kNoHit || guardsPass<COUNT>(sv, r, invx, invy, invz, h, st))) return h;
         if (COUNT) st->v[C_FALLBACK]++;
     }
@@ -475,8 +505,9 @@ __device__ __forceinline__ float reflectance(float cosine, float refIdx) {
 
 // Material::scatter for the five material kinds (R/src/Material/Material.h:22-160).
 // Returns true if the path continues with `out` and `atten`; false ends it with `emit`.
-// FULL = false: no material of the scene is a PBRMaterial (texture code left out).
-template <bool COUNT, bool FULL = true>
+// FULL = false: no material of the scene is a PBRMaterial (texture code left out).  NMAP = false: the scene
+// has normal mapping switched off (the reference's behaviour), and the code for it is left out.
+template <bool COUNT, bool FULL = true, bool NMAP = true>
 __device__ __forceinline__ bool scatter(const DevScene& sc, const SceneView& sv, const Ray& in, const Surface& s,
                                         Rng& rng, Ray& out, V3& atten, V3& emit, Stats* st) {
     const float4 m0 = sv.materials[2 * s.mat], m1 = sv.materials[2 * s.mat + 1];
@@ -537,7 +568,7 @@ __device__ __forceinline__ bool scatter(const DevScene& sc, const SceneView& sv,
     if (COUNT) st->v[C_PBR]++;
     const int texD = (int)fbits(m1.y), texR = (int)fbits(m1.z), texN = (int)fbits(m1.w);
     V3 nrm = s.n;
-    if (sc.normal_mapping && texN >= 0 && s.tri >= 0) {
+    if (NMAP && sc.normal_mapping && texN >= 0 && s.tri >= 0) {
         const float4 f0 = sc.tri_frame[2 * s.tri], f1 = sc.tri_frame[2 * s.tri + 1];
         if (f0.w != 0.0f) {
             const V3 T = normalize(V3{f0.x, f0.y, f0.z}), B = normalize(V3{f1.x, f1.y, f1.z}), N = normalize(s.n);
@@ -801,7 +832,7 @@ __device__ __forceinline__ int popc64(unsigned long long m) {
 // TIME (diagnostic): instead of path counters, each wave adds up its clock ticks per operation
 // -- box bursts, primitive runs, SHADE, NEWPATH, reference-order box steps, and everything else
 // (votes, loop overhead) -- into the scheduling-statistics slots.
-template <bool LDS, bool COUNT, bool TIME = false, bool FULL = true>
+template <bool LDS, bool COUNT, bool TIME = false, bool FULL = true, bool NMAP = false>
 __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
     const DevScene& sc = a.sc;
     fillCounterLut();
@@ -831,8 +862,10 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
     V3 thr{1.f, 1.f, 1.f};
     Rng rng{0u, 0u};
     Ray r{{0.f, 0.f, 0.f}, {0.f, 0.f, 1.f}};
-    float invx = 0.f, invy = 0.f, invz = 0.f, aa = 1.f;
+    float invx = 0.f, invy = 0.f, invz = 0.f;
+    float aa = 1.f;  // dot(d, d); the spheres-only build forms it where it is needed instead
     float nox = 0.f, noy = 0.f, noz = 0.f;  // -origin / direction, for the search structure's box test
+    float epad = 0.f;                       // this ray's widening of every box (farRayPad); zero nearly always
     Hit h{0.f, kNoHit, 0.f, 0.f};
     // 0: the lane walks the search structure; 1: it walks the reference-order array (diagnostic
     // setting, zero direction component, or a re-trace after a failed guard test / NaN distance)
@@ -884,7 +917,7 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
         invx = 1.0f / r.d.x;
         invy = 1.0f / r.d.y;
         invz = 1.0f / r.d.z;
-        aa = dot(r.d, r.d);
+        if (FULL) aa = dot(r.d, r.d);
         h.t = __builtin_inff();
         h.ref = kNoHit;
         // with direction-ordered copies of the search structure: the copy for this ray's signs
@@ -892,7 +925,11 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
         nox = -(r.o.x * invx);
         noy = -(r.o.y * invy);
         noz = -(r.o.z * invz);
-        mode = (sc.force_ref || !fastTestUsable(r.o, originLimit, invx, invy, invz, nox, noy, noz)) ? 1 : 0;
+        // a ray that starts far from the scene's small primitives (farRayPad): with the tables in LDS it widens
+        // the boxes it tests; with the tables in global memory it walks the reference-order array instead
+        const float far = farRayPad(sc, r.o);
+        if (LDS) epad = far;
+        mode = (sc.force_ref || (!LDS && far != 0.0f) || !fastTestUsable(r.o, originLimit, invx, invy, invz, nox, noy, noz)) ? 1 : 0;
         op = mode ? OP_REFBOX : OP_BOX;
         if (mode) idx = 0;  // the reference-order array has one order only
         if (COUNT) st.v[C_RAYS]++;
@@ -961,6 +998,15 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
                     const uint32_t sx = (fbits(invx) >> 29) & 4u, sy = (fbits(invy) >> 29) & 4u, sz = (fbits(invz) >> 29) & 4u;
                     bool walking = op == OP_BOX;
                     uint32_t w = 0;
+                    // the addends {entry, exit}: -o/d for both, or moved apart by the ray's own widening in the
+                    // rare burst in which some lane has one
+                    f32x2 ax{nox, nox}, ay{noy, noy}, az{noz, noz};
+                    if (__ballot(walking && epad != 0.0f)) {
+                        const float ex = epad * fabsf(invx), ey = epad * fabsf(invy), ez = epad * fabsf(invz);
+                        ax = f32x2{nox - ex, nox + ex};
+                        ay = f32x2{noy - ey, noy + ey};
+                        az = f32x2{noz - ez, noz + ez};
+                    }
                     auto boxStep = [&]() {
                         if (COUNT) {
                             schedExec[5] += 1;
@@ -973,9 +1019,9 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
                             const f32x2u pz = *reinterpret_cast<const f32x2u*>(e + 24 + sz);
                             w = *reinterpret_cast<const uint32_t*>(e + 36);
                             if (COUNT && idx != walkEnd) st.v[C_NODE]++;  // the closing entry is not a box of the scene
-                            const f32x2 tx = __builtin_elementwise_fma(f32x2{px.x, px.y}, f32x2{invx, invx}, f32x2{nox, nox});
-                            const f32x2 ty = __builtin_elementwise_fma(f32x2{py.x, py.y}, f32x2{invy, invy}, f32x2{noy, noy});
-                            const f32x2 tz = __builtin_elementwise_fma(f32x2{pz.x, pz.y}, f32x2{invz, invz}, f32x2{noz, noz});
+                            const f32x2 tx = __builtin_elementwise_fma(f32x2{px.x, px.y}, f32x2{invx, invx}, ax);
+                            const f32x2 ty = __builtin_elementwise_fma(f32x2{py.x, py.y}, f32x2{invy, invy}, ay);
+                            const f32x2 tz = __builtin_elementwise_fma(f32x2{pz.x, pz.y}, f32x2{invz, invz}, az);
                             const float tn = fmaxf(fmaxf(tx.x, ty.x), fmaxf(tz.x, kTMin));
                             const float tf = fminf(fminf(tx.y, ty.y), fminf(tz.y, h.t));
                             const bool pass = tn <= tf;
@@ -1009,7 +1055,7 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
                             const float4 n0 = sv.fnodes[2 * idx], n1 = sv.fnodes[2 * idx + 1];
                             const int first = (int)fbits(n1.w);
                             if (COUNT) st.v[C_NODE]++;
-                            const bool pass = slabPassFast(n0, n1, invx, invy, invz, nox, noy, noz, h.t);
+                            const bool pass = slabPassFast<false>(n0, n1, invx, invy, invz, nox, noy, noz, h.t, 0.0f);
                             idx = pass ? idx + 1 : (int)fbits(n1.z);
                             p = first;  // read by PRIM only, which a lane enters with its leaf run's start
                             const int onward = idx >= nNodesFast ? afterWalk() : OP_BOX;
@@ -1034,7 +1080,7 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
                             // the reference-order walk tests against the running closest distance and takes
                             // every hit; the search-structure walk tests without a limit and orders the hits.
                             float t, u = mode ? h.bu : 0.0f, v = mode ? h.bv : 0.0f;
-                            if (primRoot<COUNT, FULL>(sv, ref, r, aa, mode ? h.t : __builtin_inff(), t, u, v, &st)) {
+                            if (primRoot<COUNT, FULL>(sv, ref, r, FULL ? aa : dot(r.d, r.d), mode ? h.t : __builtin_inff(), t, u, v, &st)) {
                                 bool take = true;
                                 if (!mode) {
                                     bad = t != t;
@@ -1120,7 +1166,7 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
                     lap(T_SURFACE);
                     Ray out;
                     V3 atten, emit;
-                    const bool alive = scatter<COUNT, FULL>(sc, sv, r, sf, rng, out, atten, emit, &st);
+                    const bool alive = scatter<COUNT, FULL, NMAP>(sc, sv, r, sf, rng, out, atten, emit, &st);
                     lap(T_SCATTER);
                     if (!alive) {
                         endPath(emit);
@@ -1358,13 +1404,13 @@ __global__ void __launch_bounds__(256) resolveKernel(const float4* payloads, siz
 }
 
 // ------------------------------------------------------------------ launch wrappers
-template <bool LDS, bool COUNT, bool TIME = false, bool FULL = true>
+template <bool LDS, bool COUNT, bool TIME = false, bool FULL = true, bool NMAP = false>
 static hipError_t launchWavefrontT(const RenderArgs& a, int blocks, int threads, size_t shmem, hipStream_t stream) {
     (void)hipGetLastError();  // an earlier, unrelated failure must not be reported as this launch's
     if (LDS)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(renderWavefront<LDS, COUNT, TIME, FULL>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(renderWavefront<LDS, COUNT, TIME, FULL, NMAP>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    renderWavefront<LDS, COUNT, TIME, FULL><<<blocks, threads, shmem, stream>>>(a);
+    renderWavefront<LDS, COUNT, TIME, FULL, NMAP><<<blocks, threads, shmem, stream>>>(a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const int nSlots = a.n_local_tiles * 64;
@@ -1378,6 +1424,14 @@ hipError_t launchWavefront(const RenderArgs& a, bool lds, bool count, int blocks
     if (count && a.timing)
         return lds ? launchWavefrontT<true, false, true>(a, blocks, threads, shmem, stream)
                    : launchWavefrontT<false, false, true>(a, blocks, threads, 0, stream);
+    // scenes with normal mapping switched on run the build that has the code for it (counting launches of such
+    // scenes too: the mapped normal changes the paths)
+    if (a.sc.normal_mapping && !a.timing) {
+        if (lds) return count ? launchWavefrontT<true, true, false, true, true>(a, blocks, threads, shmem, stream)
+                              : launchWavefrontT<true, false, false, true, true>(a, blocks, threads, shmem, stream);
+        return count ? launchWavefrontT<false, true, false, true, true>(a, blocks, threads, 0, stream)
+                     : launchWavefrontT<false, false, false, true, true>(a, blocks, threads, 0, stream);
+    }
     // scenes of spheres without PBR materials run a build of the loop that leaves the triangle and texture
     // code out (fewer registers held by every lane through every operation)
     const bool plain = a.sc.n_tris == 0 && !a.sc.has_pbr;

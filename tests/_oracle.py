@@ -139,6 +139,15 @@ class OracleScene:
     def set_normal_mapping(self, on):
         self.L.orc_set_normal_mapping(self.h, 1 if on else 0)
 
+    def path_rays(self, W, H, px, py, sample, max_depth=50):
+        """(rays Nx6, hits Nx2 {kind, id}, t N) of one hash-stream path."""
+        rays = np.zeros((max_depth, 6), np.float32)
+        hits = np.zeros((max_depth, 2), np.int32)
+        t = np.zeros(max_depth, np.float32)
+        self.L.orc_path_rays.argtypes = [C.c_void_p] + [C.c_int] * 7 + [C.c_void_p] * 3
+        n = self.L.orc_path_rays(self.h, W, H, px, py, sample, max_depth, max_depth, _p(rays), _p(hits), _p(t))
+        return rays[:n], hits[:n], t[:n]
+
     def dump(self):
         ns, nt, nm = (self.L.orc_num_spheres(self.h), self.L.orc_num_triangles(self.h),
                       self.L.orc_num_materials(self.h))

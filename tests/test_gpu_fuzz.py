@@ -1,7 +1,10 @@
 """Randomised worlds through the GPU path and the oracle (a slice of profiles/fuzz_parity.py, which
-ran 3,000 worlds = 27 M rays without a differing bit): spheres of every material, loose triangles,
-meshes with and without smooth normals / PBR maps / depth limits, coincident primitives, cameras
-inside and outside the world, ragged frame sizes."""
+ran 60,000 worlds = 531 M rays without a differing bit): spheres of every material, loose triangles,
+meshes with and without smooth normals / PBR maps / normal maps / depth limits, coincident primitives,
+cameras inside and outside the world, ragged frame sizes.  Seed 61890 is kept by name: paths that bounce
+inside a glass ground sphere reach the small spheres from 66 units away, where Sphere::Hit's discriminant
+(R/src/Core/Hittable.h:236-239) is so inaccurate that it reports hits for rays that pass a sphere at 1.5 radii
+-- which the search structure has to let through (a fixed padding did not)."""
 import importlib.util
 import os
 
@@ -17,7 +20,7 @@ def test_random_worlds_render_bit_exact(rt, orc, gpu_ctx):
     fuzz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fuzz)
     rays = 0
-    for seed in range(5000, 5120):
+    for seed in list(range(5000, 5120)) + [61890]:
         build = fuzz.make_builder(seed)
         a, b = rt.Scene(), orc.OracleScene()
         build(a)
