@@ -253,7 +253,7 @@ def main():
             "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_FP32_TFLOPS, 4),
             "traffic": prof.get("hbm_bytes_per_launch"),   # null when the PMC passes predate the kernel sources
-            "kernel": "rt::renderWavefront<true, false, false>",
+            "kernel": "rt::renderWavefront<true, false, false, false, false> (tables in LDS, spheres-only build)",
             "kernel_ms": round(avg_kernel_ms, 4),
             "flops_per_sample": round(flops_per_sample, 1),
             "rays_per_sample": round(counters["rays"] / counters["samples"], 3),

@@ -16,11 +16,11 @@ def sums(root):
         cur = sqlite3.connect(db_path).cursor()
         for name, value in cur.execute(
                 "select counter_name, sum(value) from counters_collection where kernel_name like "
-                "'%renderWavefront<false, false, false>%' group by counter_name"):
+                "'%renderWavefront<false, false, false,%' group by counter_name"):
             out[name] = float(value)
         if not n:
             for total, calls in cur.execute("select total_duration, total_calls from top_kernels where name like "
-                                            "'%renderWavefront<false, false, false>%'"):
+                                            "'%renderWavefront<false, false, false,%'"):
                 ms, n = total / 1e3, calls
     return out, ms, n
 

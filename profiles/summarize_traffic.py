@@ -22,7 +22,7 @@ def per_dispatch(root, counter):
     for db_path in sorted(glob.glob(os.path.join(root, "*", "*_results.db"))):
         cur = sqlite3.connect(db_path).cursor()
         total, found = 0.0, False
-        for pattern in ("%renderWavefront<true, false, false>%", "%accumulateColors%"):
+        for pattern in ("%renderWavefront<true, false, false,%", "%accumulateColors%"):
             try:
                 rows = list(cur.execute(
                     "select sum(value) / count(distinct dispatch_id) from counters_collection "
@@ -44,7 +44,7 @@ def render_kernel(root, counter):
         try:
             rows = list(cur.execute(
                 "select sum(value) / count(distinct dispatch_id) from counters_collection "
-                "where counter_name = ? and kernel_name like ?", (counter, "%renderWavefront<true, false, false>%")))
+                "where counter_name = ? and kernel_name like ?", (counter, "%renderWavefront<true, false, false,%")))
         except sqlite3.Error:
             rows = []
         if rows and rows[0][0] is not None:
