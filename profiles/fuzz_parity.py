@@ -3,7 +3,7 @@ lathe meshes with smooth or flat normals and PBR (a third of them normal-mapped)
 (inside and outside the world, with and without a lens), with and without the reference's top-level
 BVH; every accumulation image of the GPU path must equal the CPU oracle's bit for bit.
 
-Usage (GPU box): python profiles/fuzz_parity.py [first_seed] [n_seeds]
+Usage (GPU box): python profiles/fuzz_parity.py [first_seed] [n_seeds] [device]   (device: the search structure is built on the GPU)
 Prints one line per mismatch and a summary; exit code 1 if anything differed.
 """
 import os
@@ -36,6 +36,12 @@ def make_builder(seed):
         sph.append((np.array([extent / 2, -50 * extent, extent / 2], np.float32), float(np.float32(50 * extent))))
     if n_sph > 2 and rr.rand() < 0.3:  # a duplicate: coincident primitives, decided by visit order
         sph.append(sph[0])
+    shell = None
+    if seed % 5 == 1:
+        # everything inside one big sphere (glass or mirror, chosen below): paths bounce off its inside and come
+        # back to the small primitives from far away, where the reference's hit tests are least accurate
+        shell = (np.array([extent / 2] * 3, np.float32), float(np.float32(extent * float(rr.choice([3.0, 20.0, 150.0])))),
+                 int(rr.choice([1, 2])))
     tris = [(rr.rand(9) * extent).astype(np.float32) for _ in range(n_tri)]
     meshes = []
     for _ in range(n_mesh):
@@ -70,6 +76,8 @@ def make_builder(seed):
             mats.append(s.add_material(kind, col, param))
         for i, (c, r) in enumerate(sph):
             s.add_sphere(c, r, mats[i % len(mats)])
+        if shell is not None:
+            s.add_sphere(shell[0], shell[1], s.add_material(shell[2], (0.9, 0.9, 0.9), 0.0 if shell[2] == 1 else 1.5))
         for i, p in enumerate(tris):
             s.add_triangle(p, mats[(i * 5 + 1) % len(mats)])
         for k, (m, model, depth, smooth, pbr, rough) in enumerate(meshes):
@@ -95,6 +103,8 @@ def main():
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 100
     ctx = rt.Context(0)
+    if len(sys.argv) > 3 and sys.argv[3] == "device":
+        ctx.set_device_build(True)
     bad = 0
     t0 = time.perf_counter()
     fallbacks = rays = hits = 0
