@@ -3,6 +3,8 @@
 // when the HIP runtime cannot run the kernels.
 #include <hip/hip_runtime.h>
 
+#include <limits>
+
 #include <atomic>
 #include <cmath>
 #include <cstdio>
@@ -792,6 +794,13 @@ int rt_upload_scene(rt_context* ctx, rt_scene* s) {
     d.far_radius = sc.flat.far_radius;
     d.far_rmin = sc.flat.far_rmin;
     d.far_typical = sc.flat.far_typical;
+    {
+        // farRayPad() is non-zero exactly when (|o - centre| + radius) * 1.0001 > far_typical; the kernels test
+        // the squared distance against this first
+        const double reach = (double)sc.flat.far_typical / 1.0001 - (double)sc.flat.far_radius;
+        d.far_trigger2 = (sc.flat.far_spheres + sc.flat.far_tris) == 0 ? std::numeric_limits<float>::infinity()
+                                                                        : (float)(reach > 0 ? reach * reach * 0.9999 : 0.0);
+    }
     ctx->huge_coords = hugeCoords;
     d.n_spheres = (int)sc.spheres.size();
     d.n_tris = (int)sc.triangles.size();

@@ -39,6 +39,7 @@ struct DevScene {
     // does not cover; FlatScene::far_* on the host, farRayPad() in the kernels)
     int far_spheres, far_tris;
     float far_center[3], far_radius, far_rmin, far_typical;
+    float far_trigger2;       // squared distance from far_center beyond which a ray origin gets a widening (+inf: never)
     float origin_limit;       // rays starting further than this from the coordinate origin (any axis) walk `nodes`
     float cam[22];            // origin, lowerLeftCorner, horizontal, vertical, u, v, w, lensRadius
     float bg[3];

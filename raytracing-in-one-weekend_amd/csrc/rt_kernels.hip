@@ -189,6 +189,11 @@ __device__ __forceinline__ float boxSlack(float epad, float invx, float invy, fl
 // boxes are padded for D = far_typical (the eye and the scene's own primitives are within that); a ray
 // that starts further from the primitives concerned (bounded by far_center / far_radius; far_rmin = the
 // smallest radius, which needs most) adds the difference.  Zero nearly always.
+// True if farRayPad(o) is not zero (a handful of instructions, for every ray).
+__device__ __forceinline__ bool startsFar(const DevScene& sc, const V3& o) {
+    const float dx = o.x - sc.far_center[0], dy = o.y - sc.far_center[1], dz = o.z - sc.far_center[2];
+    return (dx * dx + dy * dy) + dz * dz > sc.far_trigger2;
+}
 __device__ __forceinline__ float farRayPad(const DevScene& sc, const V3& o) {
     if ((sc.far_spheres | sc.far_tris) == 0) return 0.0f;
     const float dx = o.x - sc.far_center[0], dy = o.y - sc.far_center[1], dz = o.z - sc.far_center[2];
@@ -389,7 +394,7 @@ __device__ __forceinline__ Hit closestHit(const DevScene& sc, const SceneView& s
     if (!sc.force_ref &&
         fastTestUsable(r.o, sc.origin_limit, invx, invy, invz, -(r.o.x * invx), -(r.o.y * invy), -(r.o.z * invz))) {
         bool bad = false;
-        Hit h = traverseFast<COUNT>(sv, sc.n_fast_nodes, r, invx, invy, invz, a, farRayPad(sc, r.o), bad, st);
+        Hit h = traverseFast<COUNT>(sv, sc.n_fast_nodes, r, invx, invy, invz, a, startsFar(sc, r.o) ? farRayPad(sc, r.o) : 0.0f, bad, st);
         if (!bad && (h.ref == kNoHit || guardsPass<COUNT>(sv, r, invx, invy, invz, h, st))) return h;
         if (COUNT) st->v[C_FALLBACK]++;
     }
@@ -927,9 +932,9 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
         noz = -(r.o.z * invz);
         // a ray that starts far from the scene's small primitives (farRayPad): with the tables in LDS it widens
         // the boxes it tests; with the tables in global memory it walks the reference-order array instead
-        const float far = farRayPad(sc, r.o);
-        if (LDS) epad = far;
-        mode = (sc.force_ref || (!LDS && far != 0.0f) || !fastTestUsable(r.o, originLimit, invx, invy, invz, nox, noy, noz)) ? 1 : 0;
+        // tables in LDS: the widening itself, branch-free; tables in global memory: only whether there is one
+        if (LDS) epad = farRayPad(sc, r.o);
+        mode = (sc.force_ref || (!LDS && startsFar(sc, r.o)) || !fastTestUsable(r.o, originLimit, invx, invy, invz, nox, noy, noz)) ? 1 : 0;
         op = mode ? OP_REFBOX : OP_BOX;
         if (mode) idx = 0;  // the reference-order array has one order only
         if (COUNT) st.v[C_RAYS]++;
