@@ -551,7 +551,7 @@ void Scene::buildFastStructure() {
     // 145 -> 141 ms for 2 s more build time and 3 GB, so beyond 2 M entries the copies are not made;
     // Cornell + vase unchanged (14 instead of 21 box tests per ray, 296 ms either way).
     // (the LDS form of the entries also needs (nE + 1) * 40 and the leaf references to fit 16 bits)
-    const bool fitsLds = ldsBytes <= 72 * 1024 && (nE + 1) * 40 <= 0xFFFF && f.fast_refs.size() < 0xFFFE;
+    const bool fitsLds = ldsBytes <= 72 * 1024 && (nE + 1) * 40 + 4096 <= 0xFFFF && f.fast_refs.size() < 0xFFFE;
     const bool wantOct = octEnv ? std::atoi(octEnv) != 0 : (!fitsLds && nE <= (1u << 21));
     if (wantOct && nE * 8 + 8 < 0x7FFFFFFFu) {
         const uint32_t stride = (uint32_t)nE + 1, total = 8 * stride;

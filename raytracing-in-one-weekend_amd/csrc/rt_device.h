@@ -94,10 +94,11 @@ inline size_t ldsSceneBytes(const DevScene& s, bool with_reference_arrays = true
     return n;
 }
 
-// The LDS walk entries hold the skip link as a 16-bit byte offset and the leaf run's start as a 16-bit
+// The LDS walk entries hold the skip link as a 16-bit LDS address (the entries come first in the kernel's
+// dynamic LDS, after at most 4 KiB of static variables) and the leaf run's start as a 16-bit
 // index (0xFFFE and 0xFFFF are reserved): scenes beyond either keep their tables in global memory.
 inline bool ldsWalkEntriesFit(const DevScene& s) {
-    return ((size_t)s.n_fast_nodes + 1) * 40 <= 0xFFFF && s.n_fast_refs < 0xFFFE;
+    return ((size_t)s.n_fast_nodes + 1) * 40 + 4096 <= 0xFFFF && s.n_fast_refs < 0xFFFE;
 }
 
 }  // namespace rt

@@ -659,6 +659,9 @@ extern __shared__ float4 rt_lds[];
 constexpr int kWalkEntryBytes = 40;
 constexpr uint32_t kWalkNoLeaf = 0xFFFFu, kWalkEnd = 0xFFFEu;
 
+typedef __attribute__((address_space(3))) const char* LdsBytes;
+__device__ __forceinline__ uint32_t ldsAddress(const void* p) { return (uint32_t)(uintptr_t)(LdsBytes)p; }
+
 // Stages the scene tables into LDS and returns views into it (layout = ldsSceneBytes()).
 __device__ __forceinline__ SceneView stageScene(const DevScene& sc, bool withReferenceArrays, bool walkEntries = false) {
     char* base = reinterpret_cast<char*>(rt_lds);
@@ -684,6 +687,7 @@ __device__ __forceinline__ SceneView stageScene(const DevScene& sc, bool withRef
     if (walkEntries) {
         const int n = sc.n_fast_nodes;
         uint32_t* dst = reinterpret_cast<uint32_t*>(base + off);
+        const uint32_t at = ldsAddress(dst);  // skip links are LDS addresses, as a lane's `idx` is
         off += ((n + 1) * kWalkEntryBytes + 15) & ~15;
         for (int i = tid; i <= n; i += nt) {
             uint32_t* e = dst + 10 * i;
@@ -696,12 +700,12 @@ __device__ __forceinline__ SceneView stageScene(const DevScene& sc, bool withRef
                 e[4] = fbits(n0.w);
                 e[6] = e[8] = fbits(n1.x);
                 e[7] = fbits(n1.y);
-                e[9] = (((int)first < 0 ? kWalkNoLeaf : first) << 16) | ((skip < (uint32_t)n ? skip : (uint32_t)n) * kWalkEntryBytes);
+                e[9] = (((int)first < 0 ? kWalkNoLeaf : first) << 16) | (at + (skip < (uint32_t)n ? skip : (uint32_t)n) * kWalkEntryBytes);
             } else {
                 const uint32_t lo = fbits(-__builtin_inff()), hi = fbits(__builtin_inff());
                 e[0] = e[2] = e[3] = e[5] = e[6] = e[8] = lo;
                 e[1] = e[4] = e[7] = hi;
-                e[9] = (kWalkEnd << 16) | (uint32_t)(n * kWalkEntryBytes);
+                e[9] = (kWalkEnd << 16) | (at + (uint32_t)(n * kWalkEntryBytes));
             }
         }
         v.wnodes = reinterpret_cast<const char*>(dst);
@@ -848,10 +852,11 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
         sv = globalView(sc);
     }
     const int lane = threadIdx.x & 63;
-    // `idx` of a lane that walks the search structure: the entry's number, or with the tables in LDS its
-    // byte offset into the walk entries; walkEnd is the value that means "past the last entry"
+    // `idx` of a lane that walks the search structure: the entry's number, or with the tables in LDS the
+    // LDS address of its walk entry; walkEnd is the value that means "past the last entry"
     const int nNodesRef = sc.n_nodes, nNodesFast = sc.n_fast_nodes;
-    const int walkEnd = LDS ? nNodesFast * kWalkEntryBytes : nNodesFast;
+    const int walkBegin = LDS ? (int)ldsAddress(sv.wnodes) : 0;
+    const int walkEnd = LDS ? walkBegin + nNodesFast * kWalkEntryBytes : nNodesFast;
     const float originLimit = sc.origin_limit;
     const int nTiles = a.n_local_tiles;
     const unsigned int nChunks = (unsigned int)nTiles * (unsigned int)a.n_samples;  // 64 units each
@@ -926,7 +931,7 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
         h.t = __builtin_inff();
         h.ref = kNoHit;
         // with direction-ordered copies of the search structure: the copy for this ray's signs
-        idx = LDS ? 0 : ((r.d.x < 0.0f ? 1 : 0) | (r.d.y < 0.0f ? 2 : 0) | (r.d.z < 0.0f ? 4 : 0)) * sc.fast_oct_stride;
+        idx = LDS ? walkBegin : ((r.d.x < 0.0f ? 1 : 0) | (r.d.y < 0.0f ? 2 : 0) | (r.d.z < 0.0f ? 4 : 0)) * sc.fast_oct_stride;
         nox = -(r.o.x * invx);
         noy = -(r.o.y * invy);
         noz = -(r.o.z * invz);
@@ -1018,11 +1023,12 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
                             schedLanes[5] += popc64(__ballot(walking));
                         }
                         if (walking) {
-                            const char* e = sv.wnodes + idx;
-                            const f32x2u px = *reinterpret_cast<const f32x2u*>(e + sx);
-                            const f32x2u py = *reinterpret_cast<const f32x2u*>(e + 12 + sy);
-                            const f32x2u pz = *reinterpret_cast<const f32x2u*>(e + 24 + sz);
-                            w = *reinterpret_cast<const uint32_t*>(e + 36);
+                            const LdsBytes e = (LdsBytes)(uintptr_t)(uint32_t)idx;
+                            typedef __attribute__((address_space(3))) const float* LdsFloats;
+                            typedef __attribute__((address_space(3))) const uint32_t* LdsWord;
+                            const LdsFloats qx = (LdsFloats)(e + sx), qy = (LdsFloats)(e + 12 + sy), qz = (LdsFloats)(e + 24 + sz);
+                            const f32x2u px{qx[0], qx[1]}, py{qy[0], qy[1]}, pz{qz[0], qz[1]};
+                            w = *(LdsWord)(e + 36);
                             if (COUNT && idx != walkEnd) st.v[C_NODE]++;  // the closing entry is not a box of the scene
                             const f32x2 tx = __builtin_elementwise_fma(f32x2{px.x, px.y}, f32x2{invx, invx}, ax);
                             const f32x2 ty = __builtin_elementwise_fma(f32x2{py.x, py.y}, f32x2{invy, invy}, ay);
