@@ -1166,34 +1166,42 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
             } while (popc64(__ballot(op == OP_REFBOX)) >= keep && keep > 0);
             lap(T_REFBOX);
         } else if (chosen == OP_SHADE) {
-            if (op == OP_SHADE) {
-                const bool vouched = mode != 0 || guardsPass<COUNT, FULL>(sv, r, invx, invy, invz, h, &st);
-                lap(T_GUARD);
-                if (!vouched) {
-                    retraceInReferenceOrder();
-                } else {
-                    if (COUNT) st.v[C_HITS]++;
-                    Surface sf = surfaceAt<FULL>(sc, sv, r, h);
-                    lap(T_SURFACE);
-                    Ray out;
-                    V3 atten, emit;
-                    const bool alive = scatter<COUNT, FULL, NMAP>(sc, sv, r, sf, rng, out, atten, emit, &st);
-                    lap(T_SCATTER);
-                    if (!alive) {
-                        endPath(emit);
-                    } else {
-                        thr = thr * atten;
-                        r = out;
-                        depth -= 1;
-                        if (depth <= 0) {
-                            if (COUNT) st.v[C_CUTOFF]++;
-                            endPath(V3{0.0f, 0.0f, 0.0f});
-                        } else {
-                            lap(T_SHADE_TAIL);
-                            startRay();
-                            lap(T_RAYSETUP);
-                        }
-                    }
+            // Flat on purpose (one level of conditions, outcomes chosen by selects): every level of a nest makes
+            // the compiler copy the whole lane state.
+            const bool shading = op == OP_SHADE;
+            bool vouched = false;
+            if (shading) vouched = mode != 0 || guardsPass<COUNT, FULL>(sv, r, invx, invy, invz, h, &st);
+            lap(T_GUARD);
+            if (shading & !vouched) retraceInReferenceOrder();
+            if (shading & vouched) {
+                if (COUNT) st.v[C_HITS]++;
+                Surface sf = surfaceAt<FULL>(sc, sv, r, h);
+                lap(T_SURFACE);
+                Ray out{r.o, r.d};
+                V3 atten{1.0f, 1.0f, 1.0f}, emit;
+                const bool alive = scatter<COUNT, FULL, NMAP>(sc, sv, r, sf, rng, out, atten, emit, &st);
+                lap(T_SCATTER);
+                // The path goes on with throughput x attenuation and the scattered ray, unless it was absorbed
+                // (terminal radiance `emit`) or has used up its depth (terminal radiance 0 = `emit` of a
+                // scattering material, times the attenuated throughput as the reference forms it).
+                if (alive) {
+                    thr = thr * atten;
+                    depth -= 1;
+                }
+                const bool ends = !alive | (depth <= 0);
+                if (COUNT && alive && depth <= 0) st.v[C_CUTOFF]++;
+                if (ends) {
+                    const V3 c = thr * emit;
+                    a.colors[unit] = make_float4(c.x, c.y, c.z, 0.f);
+                }
+                r = out;
+                lap(T_SHADE_TAIL);
+                startRay();  // for a path that ends too: its lane state is dead, and NEWPATH overwrites it
+                lap(T_RAYSETUP);
+                if (ends) {
+                    if (COUNT) st.v[C_RAYS]--;
+                    depth = 0;
+                    op = OP_NEWPATH;
                 }
             }
             lap(T_SHADE_TAIL);
@@ -1230,32 +1238,30 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
                 }
             }
             lap(T_REFILL);
-            if (want) {
-                const int rankInMask =
-                    __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                const int l = chunkNext + rankInMask;  // pixel inside the tile
-                if (chunk < 0) {
-                    op = OP_DONE;
-                } else if (l < 64) {
-                    const int px = chunkX0 + (l & 7), py = chunkY0 + (l >> 3);
-                    unit = (unsigned int)chunk * 64u + (unsigned int)l;
-                    if (chunkInside && px < a.width && py < a.height) {
-                        rng.init((uint32_t)px, (uint32_t)py, chunkSample);
-                        if (COUNT) st.v[C_SAMPLES]++;
-                        // u is drawn before v (R/src/Core/Raytracer.cpp:86-87)
-                        float u = ((float)px + rng.next()) / (float)(a.width - 1);
-                        float v = ((float)py + rng.next()) / (float)(a.height - 1);
-                        r = cameraRay(sc, u, v, rng);
-                        thr = V3{1.0f, 1.0f, 1.0f};
-                        depth = a.max_depth;
-                        if (depth <= 0) {
-                            if (COUNT) st.v[C_CUTOFF]++;
-                            endPath(V3{0.0f, 0.0f, 0.0f});
-                        } else {
-                            startRay();
-                        }
-                    }  // else not a pixel of the image: this lane asks again
-                }      // else the chunk ran out before this lane's turn: it asks again
+            // One predicate for "this lane starts a path now", instead of nested conditions: every level of
+            // a nest makes the compiler copy the whole lane state.  A lane whose turn comes after the chunk
+            // ran out, or whose pixel lies outside the image, simply asks again.
+            const int rankInMask =
+                __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            const int l = chunkNext + rankInMask;  // pixel inside the tile
+            const int px = chunkX0 + (l & 7), py = chunkY0 + (l >> 3);
+            if (want & (chunk < 0)) op = OP_DONE;
+            if (want & (chunk >= 0) & (l < 64) & chunkInside & (px < a.width) & (py < a.height)) {
+                unit = (unsigned int)chunk * 64u + (unsigned int)l;
+                rng.init((uint32_t)px, (uint32_t)py, chunkSample);
+                if (COUNT) st.v[C_SAMPLES]++;
+                // u is drawn before v (R/src/Core/Raytracer.cpp:86-87)
+                float u = ((float)px + rng.next()) / (float)(a.width - 1);
+                float v = ((float)py + rng.next()) / (float)(a.height - 1);
+                r = cameraRay(sc, u, v, rng);
+                thr = V3{1.0f, 1.0f, 1.0f};
+                depth = a.max_depth;
+                if (depth <= 0) {
+                    if (COUNT) st.v[C_CUTOFF]++;
+                    endPath(V3{0.0f, 0.0f, 0.0f});
+                } else {
+                    startRay();
+                }
             }
             chunkNext += popc64(m);
             lap(T_CAMERA);
