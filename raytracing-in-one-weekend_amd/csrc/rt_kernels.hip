@@ -1140,7 +1140,8 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
                 }
                 lap(T_REST);
             }
-        } else if (chosen == OP_REFBOX) {
+        }
+        if (chosen == OP_REFBOX) {
             // Reference-order array: the reference's own test; list entries have no box.
             const int keep = boxKeep < cRef ? boxKeep : cRef;
             do {
@@ -1165,7 +1166,8 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
                 }
             } while (popc64(__ballot(op == OP_REFBOX)) >= keep && keep > 0);
             lap(T_REFBOX);
-        } else if (chosen == OP_SHADE) {
+        }
+        if (chosen == OP_SHADE) {
             // Flat on purpose (one level of conditions, outcomes chosen by selects): every level of a nest makes
             // the compiler copy the whole lane state.
             const bool shading = op == OP_SHADE;
@@ -1205,7 +1207,8 @@ __global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
                 }
             }
             lap(T_SHADE_TAIL);
-        } else {  // OP_NEWPATH: the next unit for every waiting lane, in lane order, and its camera ray
+        }
+        if (chosen == OP_NEWPATH) {  // the next unit for every waiting lane, in lane order, and its camera ray
             const bool want = op == OP_NEWPATH;
             if (want && depth > 0) {  // the path this lane holds ended on the background
                 if (COUNT) st.v[C_MISS]++;
