@@ -210,11 +210,12 @@ def test_render_cover_bit_exact(rt, orc, scenes, gpu_ctx, wrap):
 
 
 def test_render_ragged_size_and_depths(rt, orc, scenes, gpu_ctx):
-    """Width and height that are not multiples of the 8x8 tile; max depth 1, 2 and 5."""
+    """Width and height that are not multiples of the 8x8 tile; max depth 0 (rayColor returns black before any
+    ray is cast, R/src/Core/Raytracer.cpp:5-6), 1, 2 and 5."""
     w, h = 101, 59
     a, b = both(rt, orc, lambda s: scenes.cover_scene(s, w, h, wrap_bvh=True))
     gpu_ctx.upload_scene(a)
-    for depth in (1, 2, 5):
+    for depth in (0, 1, 2, 5):
         got = render_gpu(gpu_ctx, w, h, 0, 2, depth)
         want, _, _ = b.render(w, h, 0, 2, depth, rng_mode=1, order=1, threads=8)
         assert np.array_equal(bits(got[..., :3]), bits(want[..., :3])), depth
