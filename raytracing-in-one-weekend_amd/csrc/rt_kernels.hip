@@ -653,7 +653,7 @@ extern __shared__ float4 rt_lds[];
 //   {min.x, max.x, min.x,  min.y, max.y, min.y,  min.z, max.z, min.z,  first_ref << 16 | skip}
 // A lane reads each axis as the two dwords that start at 0 (direction component positive) or 4 bytes
 // (negative) into the triple, which hands it {entry plane, exit plane} with no comparison.  `skip` is
-// the byte offset of the entry to go on with after a failed test; first_ref is 0xFFFF for an entry
+// the LDS address of the entry to go on with after a failed test; first_ref is 0xFFFF for an entry
 // without a leaf run.  The table ends with an entry every ray passes whose first_ref is kWalkEnd:
 // reaching it is how a lane learns that its walk is over.
 constexpr int kWalkEntryBytes = 40;
