@@ -48,7 +48,7 @@ def flops_from_counters(c):
 
 
 SHADER_CLOCK_HZ = 2.4e9  # MI355X peak engine clock, the one the 157.3 TFLOP/s figure is quoted at
-KERNEL_SOURCES = ("rt_kernels.hip", "rt_device.h")
+KERNEL_SOURCES = ("rt_kernels.hip", "rt_device.h", "Makefile")  # the Makefile holds the kernels' compiler flags
 
 
 def kernel_source_hash():

@@ -5,7 +5,7 @@
 set -eu
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 TMP=$(mktemp -d)
-/opt/rocm/bin/hipcc -std=c++17 -O3 -fPIC -ffp-contract=off -fno-fast-math --offload-arch=gfx950 --cuda-device-only -S \
+/opt/rocm/bin/hipcc -std=c++17 -O3 -fPIC -O1 -ffp-contract=off -fno-fast-math --offload-arch=gfx950 --cuda-device-only -S \
     "$ROOT/raytracing-in-one-weekend_amd/csrc/rt_kernels.hip" -o "$TMP/k.s" 2>/dev/null
 echo "# rt_kernels.hip sha256 $(sha256sum "$ROOT/raytracing-in-one-weekend_amd/csrc/rt_kernels.hip" | cut -c1-16)"
 awk '/^amdhsa.kernels:/,/^amdhsa.target:/' "$TMP/k.s" | awk '

@@ -207,11 +207,13 @@ int launch(rt_context* ctx, rt::RenderArgs& a, bool count, const Workspace* fixe
     a.knob[1] = envInt("RT_SHADE_MIN", 32);
     a.knob[3] = std::max(1, envInt("RT_PRIM_KEEP", 16));
     a.timing = envInt("RT_TIMING", 0);
-    int wfThreads = envInt("RT_THREADS", 512);
-    if (wfThreads < 64 || wfThreads > WF_MAX_THREADS || wfThreads % 64 != 0) wfThreads = 512;
+    // tables in LDS: three 512-thread workgroups per CU = 6 waves per SIMD (two when the staged scene is too
+    // big); tables in global memory: eight 256-thread workgroups = 8 waves per SIMD (see renderWavefront)
+    const int defThreads = ctx->use_lds ? 512 : 256;
+    int wfThreads = envInt("RT_THREADS", defThreads);
+    if (wfThreads < 64 || wfThreads > WF_MAX_THREADS || wfThreads % 64 != 0) wfThreads = defThreads;
     const int wfWaves = wfThreads / 64;
-    // three 512-thread workgroups per CU = 6 waves per SIMD (two when the staged scene is too big)
-    const int perCu = ctx->use_lds && ctx->lds_need > kLdsThreeGroups ? 2 : 3;
+    const int perCu = !ctx->use_lds ? 8 * 256 / wfThreads : (ctx->lds_need > kLdsThreeGroups ? 2 : 3);
     const int maxBlocks = ctx->n_cus * envInt("RT_BLOCKS_PER_CU", perCu);
 
     // The kernel writes one radiance per pixel sample into the colour buffer and a second kernel

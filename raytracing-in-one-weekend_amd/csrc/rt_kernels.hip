@@ -832,17 +832,23 @@ __device__ __forceinline__ int popc64(unsigned long long m) {
     return c;
 }
 
-// 512-thread workgroups, three per CU = 6 waves per SIMD (80 registers per lane, a few cold values
-// spilled).  Measured on the cover scene: 4 waves per SIMD 37.6 ms, 6 waves 33.1 ms, 8 waves
-// (64 registers, heavy spilling) 60 ms.
-#ifndef WF_BOUNDS
-#define WF_BOUNDS 512, 6
+// Occupancy.  Tables in LDS: 512-thread workgroups, three per CU = 6 waves per SIMD (80 registers per lane).
+// Measured on the cover scene: 4 waves per SIMD 37.6 ms, 6 waves 33.1 ms, and at the end of round 2 (25.7 ms with 6)
+// 7 waves 28.1 ms, 8 waves 28.4 ms: the LDS-resident loop is issue-bound and more waves only add contention.
+// Tables in global memory: 8 waves per SIMD (64 registers per lane), 256-thread workgroups, eight per CU -- there
+// the loads go to L1 / L2 and two more waves hide their latency: Cornell + vase 265.8 -> 239.8 ms, 1 M triangles
+// 60.3 -> 58.5 ms, 10 M triangles unchanged (142 ms).
+#ifndef WF_WAVES_LDS
+#define WF_WAVES_LDS 6
+#endif
+#ifndef WF_WAVES_GLOBAL
+#define WF_WAVES_GLOBAL 8
 #endif
 // TIME (diagnostic): instead of path counters, each wave adds up its clock ticks per operation
 // -- box bursts, primitive runs, SHADE, NEWPATH, reference-order box steps, and everything else
 // (votes, loop overhead) -- into the scheduling-statistics slots.
 template <bool LDS, bool COUNT, bool TIME = false, bool FULL = true, bool NMAP = false>
-__global__ void __launch_bounds__(WF_BOUNDS) renderWavefront(RenderArgs a) {
+__global__ void __launch_bounds__(WF_MAX_THREADS, LDS ? WF_WAVES_LDS : WF_WAVES_GLOBAL) renderWavefront(RenderArgs a) {
     const DevScene& sc = a.sc;
     fillCounterLut();
     SceneView sv;
