@@ -308,6 +308,10 @@ int rt_read_rgba8(rt_context* ctx, int samples_per_pixel, uint8_t* dst);
  * its bytes to glTexImage2D (RaytracingApplication.cpp:194) and has no file writer; this is the
  * image.ppm of the book the reference follows, for headless use. */
 int rt_write_ppm(const char* path, int width, int height, const uint8_t* rgba8);
+/* The same buffer as an 8-bit RGB PNG (top row first, alpha dropped; the pixel data goes into stored, i.e.
+ * uncompressed, deflate blocks, which every PNG reader accepts).  Host only.  Like rt_write_ppm it stands where
+ * the reference uploads its bytes to a texture (RaytracingApplication.cpp:194) and writes no file. */
+int rt_write_png(const char* path, int width, int height, const uint8_t* rgba8);
 
 /* Device-side resolve of `world` rank payloads laid end to end (the output of an all-gather
  * of every rank's accumulation buffer) into a row-major RGBA32F device image. */

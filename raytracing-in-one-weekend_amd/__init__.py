@@ -102,6 +102,7 @@ SYMBOLS = {
     "rt_read_accum_rgba32f": (_I, [_VP, _VP]),
     "rt_read_rgba8": (_I, [_VP, _I, _VP]),
     "rt_write_ppm": (_I, [C.c_char_p, _I, _I, _VP]),
+    "rt_write_png": (_I, [C.c_char_p, _I, _I, _VP]),
     "rt_resolve_gathered": (_I, [_VP, _VP, _I, _VP]),
     "rt_resolve_gathered_rgba8": (_I, [_VP, _VP, _I, _I, _VP]),
     "rt_group_create": (_I, [_I, _VP, C.POINTER(_VP)]),
@@ -535,6 +536,14 @@ def write_ppm(path, rgba8):
     if a.ndim != 3 or a.shape[2] != 4:
         raise ValueError("expected an HxWx4 uint8 image")
     _check(lib.rt_write_ppm(os.fsencode(path), a.shape[1], a.shape[0], _p(a)))
+
+
+def write_png(path, rgba8):
+    """8-bit RGB PNG (top row first, uncompressed) of an HxWx4 uint8 image whose row 0 is the bottom row."""
+    a = np.ascontiguousarray(rgba8, dtype=np.uint8)
+    if a.ndim != 3 or a.shape[2] != 4:
+        raise ValueError("expected an HxWx4 uint8 image")
+    _check(lib.rt_write_png(os.fsencode(path), a.shape[1], a.shape[0], _p(a)))
 
 
 def accum_bytes(width, height, world=1):

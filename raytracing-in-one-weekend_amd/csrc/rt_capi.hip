@@ -1027,6 +1027,88 @@ int rt_write_ppm(const char* path, int width, int height, const uint8_t* rgba8) 
     return RT_OK;
 }
 
+namespace {
+uint32_t crc32Of(const uint8_t* p, size_t n, uint32_t crc = 0) {
+    static uint32_t table[256];
+    static bool ready = false;
+    if (!ready) {
+        for (uint32_t i = 0; i < 256; i++) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; k++) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+            table[i] = c;
+        }
+        ready = true;
+    }
+    crc = ~crc;
+    for (size_t i = 0; i < n; i++) crc = table[(crc ^ p[i]) & 0xFFu] ^ (crc >> 8);
+    return ~crc;
+}
+void putBe32(std::vector<uint8_t>& v, uint32_t x) {
+    for (int k = 3; k >= 0; k--) v.push_back((uint8_t)(x >> (8 * k)));
+}
+void pngChunk(std::vector<uint8_t>& file, const char type[4], const std::vector<uint8_t>& data) {
+    putBe32(file, (uint32_t)data.size());
+    const size_t at = file.size();
+    file.insert(file.end(), type, type + 4);
+    file.insert(file.end(), data.begin(), data.end());
+    putBe32(file, crc32Of(file.data() + at, file.size() - at));
+}
+}  // namespace
+
+int rt_write_png(const char* path, int width, int height, const uint8_t* rgba8) {
+    if (!path || !rgba8 || width <= 0 || height <= 0) return fail(RT_ERR_INVALID, "bad arguments");
+    if ((long long)width * height > (1ll << 28)) return fail(RT_ERR_LIMIT, "image too large for the PNG writer");
+    // scanlines, top row first, each with filter type 0 in front
+    const size_t row = 1 + (size_t)width * 3;
+    std::vector<uint8_t> raw(row * (size_t)height);
+    for (int y = 0; y < height; y++) {
+        uint8_t* out = raw.data() + (size_t)y * row;
+        const uint8_t* in = rgba8 + (size_t)(height - 1 - y) * width * 4;  // the buffer's row 0 is the bottom row
+        *out++ = 0;
+        for (int x = 0; x < width; x++, in += 4, out += 3) {
+            out[0] = in[0];
+            out[1] = in[1];
+            out[2] = in[2];
+        }
+    }
+    // a zlib stream of stored (uncompressed) deflate blocks: any PNG reader takes it, and a frame is written in
+    // the time it takes to copy it
+    std::vector<uint8_t> z;
+    z.reserve(raw.size() + raw.size() / 65535 * 5 + 16);
+    z.push_back(0x78);
+    z.push_back(0x01);
+    uint32_t a1 = 1, a2 = 0;  // Adler-32 of the raw bytes
+    for (size_t at = 0; at < raw.size() || at == 0;) {
+        const size_t n = std::min<size_t>(65535, raw.size() - at);
+        z.push_back(at + n >= raw.size() ? 1 : 0);
+        z.push_back((uint8_t)(n & 0xFF));
+        z.push_back((uint8_t)(n >> 8));
+        z.push_back((uint8_t)(~n & 0xFF));
+        z.push_back((uint8_t)((~n >> 8) & 0xFF));
+        z.insert(z.end(), raw.begin() + (long)at, raw.begin() + (long)(at + n));
+        for (size_t i = at; i < at + n; i++) {
+            a1 = (a1 + raw[i]) % 65521u;
+            a2 = (a2 + a1) % 65521u;
+        }
+        at += n;
+        if (n == 0) break;
+    }
+    putBe32(z, (a2 << 16) | a1);
+    std::vector<uint8_t> file = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+    std::vector<uint8_t> ihdr;
+    putBe32(ihdr, (uint32_t)width);
+    putBe32(ihdr, (uint32_t)height);
+    ihdr.insert(ihdr.end(), {8, 2, 0, 0, 0});  // 8 bits per channel, RGB, deflate, adaptive filtering, no interlace
+    pngChunk(file, "IHDR", ihdr);
+    pngChunk(file, "IDAT", z);
+    pngChunk(file, "IEND", {});
+    FILE* f = std::fopen(path, "wb");
+    if (!f) return fail(RT_ERR_INVALID, std::string("cannot open ") + path);
+    const bool ok = std::fwrite(file.data(), 1, file.size(), f) == file.size();
+    if (std::fclose(f) != 0 || !ok) return fail(RT_ERR_INVALID, std::string("short write to ") + path);
+    return RT_OK;
+}
+
 int rt_resolve_gathered(rt_context* ctx, const void* device_payloads, int world, void* device_rgba32f) {
     if (!ctx || !device_payloads || !device_rgba32f) return fail(RT_ERR_INVALID, "null argument");
     if (world != ctx->world) return fail(RT_ERR_INVALID, "world differs from rt_set_target()");

@@ -57,6 +57,37 @@ def test_product_library_does_not_link_the_oracle(rt):
     assert "orc_" not in syms
 
 
+def test_png_writer_round_trip(rt, tmp_path):
+    """The PNG the library writes is read back by an independent reader (zlib + the chunk layout, here) and by
+    the library's own decoder: RGB, 8 bits, top row first (the buffer's row 0 is the bottom row), alpha dropped;
+    a frame larger than one stored deflate block (65,535 bytes) included."""
+    import struct
+    import zlib
+    import numpy as np
+    r = np.random.RandomState(1)
+    for h, w in ((5, 7), (1, 1), (200, 333)):
+        img = r.randint(0, 256, size=(h, w, 4)).astype(np.uint8)
+        path = tmp_path / f"image_{w}x{h}.png"
+        rt.write_png(str(path), img)
+        data = path.read_bytes()
+        assert data[:8] == b"\x89PNG\r\n\x1a\n"
+        at, chunks = 8, []
+        while at < len(data):
+            n, typ = struct.unpack(">I4s", data[at:at + 8])
+            body = data[at + 8:at + 8 + n]
+            assert struct.unpack(">I", data[at + 8 + n:at + 12 + n])[0] == zlib.crc32(typ + body)
+            chunks.append((typ, body))
+            at += 12 + n
+        assert [c[0] for c in chunks] == [b"IHDR", b"IDAT", b"IEND"]
+        assert struct.unpack(">IIBBBBB", chunks[0][1]) == (w, h, 8, 2, 0, 0, 0)
+        raw = np.frombuffer(zlib.decompress(chunks[1][1]), np.uint8).reshape(h, 1 + 3 * w)
+        assert not raw[:, 0].any()
+        assert np.array_equal(raw[:, 1:].reshape(h, w, 3), img[::-1, :, :3])
+        assert np.array_equal(rt.image_decode(data), img[::-1, :, :3])
+    with pytest.raises(rt.RtError):
+        rt.write_png(str(tmp_path / "no_such_dir" / "x.png"), img)
+
+
 def test_ppm_writer_round_trip(rt, tmp_path):
     """P3 header, 255 maximum, top row first (the buffer's row 0 is the bottom row), alpha dropped."""
     import numpy as np
