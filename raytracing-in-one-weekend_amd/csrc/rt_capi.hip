@@ -67,8 +67,8 @@ struct rt_context {
     int force_ref = 0;
     bool huge_coords = false;
     unsigned long long sched_stats[14] = {0};  // from the last rt_count(): {executions, lanes} per operation
-    float4* colors = nullptr;  // per-sample radiance of the split mode (grown on demand)
-    size_t colors_cap = 0;     // in float4
+    rt::Radiance* colors = nullptr;  // per-sample radiance of the split mode (grown on demand)
+    size_t colors_cap = 0;           // in samples
     bool device_build = false;  // rt_upload_scene() builds the search structure on the device
     float build_ms = 0.0f;      // device time of the last such build
     void* resolved = nullptr;  // row-major image the read-out calls resolve into (grown on demand, kept)
@@ -185,8 +185,8 @@ int checkRenderState(rt_context* ctx) {
 // one-wave-per-tile kernel (kept for A/B measurements); both produce identical images.
 // Where a render call keeps the per-sample colours and the queue counter of its launches.
 struct Workspace {
-    float4* colors;        // null: the context's own buffer, grown on demand
-    size_t colors_cap;     // in float4
+    rt::Radiance* colors;  // null: the context's own buffer, grown on demand
+    size_t colors_cap;     // in samples
     unsigned int* queue;
 };
 
@@ -226,9 +226,9 @@ int launch(rt_context* ctx, rt::RenderArgs& a, bool count, const Workspace* fixe
             return fail(RT_ERR_LIMIT, "rt_render_noalloc: this context's share of the frame (" + std::to_string(nSlots) +
                                           " pixel slots) exceeds the fixed scratch of " +
                                           std::to_string(fixed->colors_cap) + " slots");
-        budget = std::min(budget, fixed->colors_cap * sizeof(float4));
+        budget = std::min(budget, fixed->colors_cap * sizeof(rt::Radiance));
     }
-    size_t maxSamples = std::max<size_t>(1, budget / ((size_t)nSlots * 16));
+    size_t maxSamples = std::max<size_t>(1, budget / ((size_t)nSlots * sizeof(rt::Radiance)));
     maxSamples = std::min<size_t>(maxSamples, (size_t)((1ll << 31) / nSlots));
     maxSamples = std::max<size_t>(1, std::min<size_t>(maxSamples, (size_t)a.n_samples));
     const int first = a.first_sample, total = a.n_samples;
@@ -240,7 +240,7 @@ int launch(rt_context* ctx, rt::RenderArgs& a, bool count, const Workspace* fixe
             if (ctx->colors) (void)hipFree(ctx->colors);
             ctx->colors = nullptr;
             ctx->colors_cap = 0;
-            HIP_TRY(hipMalloc((void**)&ctx->colors, need * sizeof(float4)));
+            HIP_TRY(hipMalloc((void**)&ctx->colors, need * sizeof(rt::Radiance)));
             ctx->colors_cap = need;
         }
         a.first_sample = first + s0;
@@ -891,7 +891,7 @@ int rt_render(rt_context* ctx, int first_sample, int n_samples, int max_depth) {
     return RT_OK;
 }
 
-size_t rt_noalloc_max_pixels(void) { return kScratchColorBytes / sizeof(float4); }
+size_t rt_noalloc_max_pixels(void) { return kScratchColorBytes / 16; }
 
 int rt_render_noalloc(rt_context* ctx, int first_sample, int n_samples, int max_depth) {
     int rc = checkRenderState(ctx);
@@ -903,7 +903,7 @@ int rt_render_noalloc(rt_context* ctx, int first_sample, int n_samples, int max_
     HIP_TRY(hipSetDevice(ctx->device));
     unsigned char* base = g_scratchPtr[ctx->device];
     if (!base) return fail(RT_ERR_STATE, "the scratch array of this device was never looked up");
-    Workspace ws{reinterpret_cast<float4*>(base + kScratchQueueBytes), kScratchColorBytes / sizeof(float4),
+    Workspace ws{reinterpret_cast<rt::Radiance*>(base + kScratchQueueBytes), kScratchColorBytes / 16,
                  reinterpret_cast<unsigned int*>(base)};
     rt::RenderArgs a = makeArgs(ctx, first_sample, n_samples, max_depth);
     HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));

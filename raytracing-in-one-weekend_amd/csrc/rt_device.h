@@ -45,6 +45,11 @@ struct DevScene {
     float bg[3];
 };
 
+// One path's radiance in the colour buffer: 12 bytes written once and read once per pixel sample.
+struct Radiance {
+    float r, g, b;
+};
+
 struct RenderArgs {
     DevScene sc;
     float4* accum;        // tiled: [local tile][lane] -> {r, g, b, samples}
@@ -62,7 +67,7 @@ struct RenderArgs {
     int timing;  // counting launches collect per-operation clock ticks instead (diagnostic)
     // per-sample radiance of the launch: colors[(sample - first_sample) * n_slots + pixel slot],
     // added to the accumulation buffer in sample order by accumulateColors()
-    float4* colors;
+    Radiance* colors;
 };
 
 // Megabytes of the fixed colour scratch behind rt_render_noalloc() (one copy per GPU in use).

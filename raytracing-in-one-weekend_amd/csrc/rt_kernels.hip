@@ -960,7 +960,7 @@ __global__ void __launch_bounds__(WF_MAX_THREADS, LDS ? WF_WAVES_LDS : WF_WAVES_
     };
     auto endPath = [&](V3 terminal) {
         const V3 c = thr * terminal;
-        a.colors[unit] = make_float4(c.x, c.y, c.z, 0.f);
+        a.colors[unit] = Radiance{c.x, c.y, c.z};
         depth = 0;  // nothing left to finish (see afterWalk)
         op = OP_NEWPATH;
     };
@@ -1200,7 +1200,7 @@ __global__ void __launch_bounds__(WF_MAX_THREADS, LDS ? WF_WAVES_LDS : WF_WAVES_
                 if (COUNT && alive && depth <= 0) st.v[C_CUTOFF]++;
                 if (ends) {
                     const V3 c = thr * emit;
-                    a.colors[unit] = make_float4(c.x, c.y, c.z, 0.f);
+                    a.colors[unit] = Radiance{c.x, c.y, c.z};
                 }
                 r = out;
                 lap(T_SHADE_TAIL);
@@ -1315,8 +1315,8 @@ __global__ void __launch_bounds__(256) accumulateColors(RenderArgs a) {
     const float4 acc = a.accum[q];
     V3 sum{acc.x, acc.y, acc.z};
     for (int s = 0; s < a.n_samples; s++) {
-        const float4 c = a.colors[(size_t)s * nSlots + q];
-        sum = sum + V3{c.x, c.y, c.z};
+        const Radiance c = a.colors[(size_t)s * nSlots + q];
+        sum = sum + V3{c.r, c.g, c.b};
     }
     a.accum[q] = make_float4(sum.x, sum.y, sum.z, (float)(a.first_sample + a.n_samples));
 }
