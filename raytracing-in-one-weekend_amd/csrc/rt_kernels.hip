@@ -1040,7 +1040,11 @@ __global__ void __launch_bounds__(WF_MAX_THREADS, LDS ? WF_WAVES_LDS : WF_WAVES_
                             const f32x2 ty = __builtin_elementwise_fma(f32x2{py.x, py.y}, f32x2{invy, invy}, ay);
                             const f32x2 tz = __builtin_elementwise_fma(f32x2{pz.x, pz.y}, f32x2{invz, invz}, az);
                             const float tn = fmaxf(fmaxf(tx.x, ty.x), fmaxf(tz.x, kTMin));
-                            const float tf = fminf(fminf(tx.y, ty.y), fminf(tz.y, h.t));
+                            // min(tz.y, h.t) on the bit patterns: h.t is never negative and neither value is a NaN
+                            // here, so the signed integer order is the float order, and fminf()'s canonicalisation
+                            // of h.t (an instruction per step) is not needed
+                            const int zi = __float_as_int(tz.y), hi = __float_as_int(h.t);
+                            const float tf = fminf(fminf(tx.y, ty.y), __int_as_float(zi < hi ? zi : hi));
                             const bool pass = tn <= tf;
                             idx = pass ? idx + kWalkEntryBytes : (int)(w & 0xFFFFu);
                             walking = !(pass && w < (kWalkNoLeaf << 16));
