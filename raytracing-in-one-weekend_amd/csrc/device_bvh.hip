@@ -257,8 +257,10 @@ __device__ __forceinline__ void writeEntry(const EmitArgs& e, const int idx[8], 
         int skip = idx[k] + count;
         if (e.copies == 8) skip = skip >= e.n_entries ? total : base + skip;  // past the end = the walk is over
         const size_t at = (size_t)(base + idx[k]);
-        e.entries[2 * at] = make_float4(mn.x, mx.x, mn.y, mx.y);
-        e.entries[2 * at + 1] = make_float4(mn.z, mx.z, __int_as_float(skip), __int_as_float(firstRef));
+        // copy k serves rays whose direction is negative on the axes of k's set bits: {entry plane, exit plane}
+        const bool nx = (k & 1) != 0, ny = (k & 2) != 0, nz = (k & 4) != 0;
+        e.entries[2 * at] = make_float4(nx ? mx.x : mn.x, nx ? mn.x : mx.x, ny ? mx.y : mn.y, ny ? mn.y : mx.y);
+        e.entries[2 * at + 1] = make_float4(nz ? mx.z : mn.z, nz ? mn.z : mx.z, __int_as_float(skip), __int_as_float(firstRef));
     }
 }
 

@@ -578,6 +578,11 @@ void Scene::buildFastStructure() {
             for (size_t e = 0; e < nE; e++) {
                 uint32_t& skip = dst[e * 8 + 6];
                 skip = skip >= nE ? total : skip + base;
+                // a copy is walked only by rays with its sign pattern, so it stores {entry plane, exit plane}
+                // per axis -- min and max swapped where the direction is negative -- and the box test needs no
+                // min / max to sort them (copy 0, all signs positive, keeps the plain layout)
+                for (int a = 0; a < 3; a++)
+                    if ((k >> a) & 1u) std::swap(dst[e * 8 + 2 * a], dst[e * 8 + 2 * a + 1]);
             }
             // the entry after the last one: x planes at +infinity, y and z planes at 0 -- the x distances
             // are both +inf or both -inf, the others finite, so the intervals never meet

@@ -9,6 +9,8 @@
 // R/ = /root/reference/Raytracing-In-A-Weekend/.
 #include "rt_device.h"
 
+#include <type_traits>
+
 namespace rt {
 
 constexpr uint32_t kNoBox = 1u << 30;
@@ -173,6 +175,17 @@ __device__ __forceinline__ bool slabPassFast(const float4& a, const float4& b, f
     const float tn = fmaxf(fmaxf(fminf(tx.x, tx.y), fminf(ty.x, ty.y)), fmaxf(fminf(tz.x, tz.y), kTMin));
     const float tf = fminf(fminf(fmaxf(tx.x, tx.y), fmaxf(ty.x, ty.y)), fminf(fmaxf(tz.x, tz.y), closest));
     return WIDE ? tn <= tf + slack : tn <= tf;
+}
+// The same test on an entry of a direction-ordered copy, whose planes are stored {entry, exit} per axis for the
+// sign pattern of the rays that walk it: nothing to sort.
+__device__ __forceinline__ bool slabPassSorted(const float4& a, const float4& b, float invx, float invy, float invz,
+                                               float nox, float noy, float noz, float closest) {
+    const f32x2 tx = __builtin_elementwise_fma(f32x2{a.x, a.y}, f32x2{invx, invx}, f32x2{nox, nox});
+    const f32x2 ty = __builtin_elementwise_fma(f32x2{a.z, a.w}, f32x2{invy, invy}, f32x2{noy, noy});
+    const f32x2 tz = __builtin_elementwise_fma(f32x2{b.x, b.y}, f32x2{invz, invz}, f32x2{noz, noz});
+    const float tn = fmaxf(fmaxf(tx.x, ty.x), fmaxf(tz.x, kTMin));
+    const float tf = fminf(fminf(tx.y, ty.y), fminf(tz.y, closest));
+    return tn <= tf;
 }
 // A box widened by e on every side is entered at most e * |1/d| earlier and left at most e * |1/d| later on
 // each axis; with the largest of the three factors for all axes the widened test is implied by
@@ -1070,30 +1083,39 @@ __global__ void __launch_bounds__(WF_MAX_THREADS, LDS ? WF_WAVES_LDS : WF_WAVES_
                     // Search structure: conservative fused box test.  An entry that passes and carries
                     // a leaf run sends the lane to PRIM; `idx` already names the entry to go on with.
                     const int keep = boxKeep < nBox ? boxKeep : nBox;  // never spin below what is available
-                    auto boxStep = [&]() {
-                        if (COUNT) {
-                            schedExec[5] += 1;
-                            schedLanes[5] += popc64(__ballot(op == OP_BOX));
-                        }
-                        if (op == OP_BOX) {
-                            const float4 n0 = sv.fnodes[2 * idx], n1 = sv.fnodes[2 * idx + 1];
-                            const int first = (int)fbits(n1.w);
-                            if (COUNT) st.v[C_NODE]++;
-                            const bool pass = slabPassFast<false>(n0, n1, invx, invy, invz, nox, noy, noz, h.t, 0.0f);
-                            idx = pass ? idx + 1 : (int)fbits(n1.z);
-                            p = first;  // read by PRIM only, which a lane enters with its leaf run's start
-                            const int onward = idx >= nNodesFast ? afterWalk() : OP_BOX;
-                            op = (pass & (first >= 0)) ? OP_PRIM : onward;
-                        }
+                    // compiled twice: for the direction-ordered copies (planes stored sorted) and for a single copy
+                    auto burst = [&](auto sortedPlanes) {
+                        auto boxStep = [&]() {
+                            if (COUNT) {
+                                schedExec[5] += 1;
+                                schedLanes[5] += popc64(__ballot(op == OP_BOX));
+                            }
+                            if (op == OP_BOX) {
+                                const float4 n0 = sv.fnodes[2 * idx], n1 = sv.fnodes[2 * idx + 1];
+                                const int first = (int)fbits(n1.w);
+                                if (COUNT) st.v[C_NODE]++;
+                                const bool pass = decltype(sortedPlanes)::value
+                                                      ? slabPassSorted(n0, n1, invx, invy, invz, nox, noy, noz, h.t)
+                                                      : slabPassFast<false>(n0, n1, invx, invy, invz, nox, noy, noz, h.t, 0.0f);
+                                idx = pass ? idx + 1 : (int)fbits(n1.z);
+                                p = first;  // read by PRIM only, which a lane enters with its leaf run's start
+                                const int onward = idx >= nNodesFast ? afterWalk() : OP_BOX;
+                                op = (pass & (first >= 0)) ? OP_PRIM : onward;
+                            }
+                        };
+                        int still;
+                        do {  // three steps per look at the lane count (1: 32.35 ms, 2: 31.75, 3: 31.6, 4: 31.7);
+                              // the look comes before the third step, whose execution hides its latency
+                            boxStep();
+                            boxStep();
+                            still = popc64(__ballot(op == OP_BOX));
+                            boxStep();
+                        } while (still >= keep && keep > 0);
                     };
-                    int still;
-                    do {  // three steps per look at the lane count (1: 32.35 ms, 2: 31.75, 3: 31.6, 4: 31.7);
-                          // the look comes before the third step, whose execution hides its latency
-                        boxStep();
-                        boxStep();
-                        still = popc64(__ballot(op == OP_BOX));
-                        boxStep();
-                    } while (still >= keep && keep > 0);
+                    if (sc.fast_oct_stride > 0)
+                        burst(std::true_type{});
+                    else
+                        burst(std::false_type{});
                     lap(T_BOX);
                 } else {
                     auto primStep = [&]() {

@@ -183,8 +183,16 @@ def test_direction_ordered_copies(rt, scenes):
     plain = {tuple(e[:6]) + (e[7],) for e in entries}
     for k in range(8):
         base = k * stride
-        c = oct_entries[base:base + stride]
-        # the same set of (box, leaf run) pairs, plus the closing entry
+        c = oct_entries[base:base + stride].copy()
+        # a copy stores {entry plane, exit plane} per axis for its sign pattern: max before min where the
+        # direction is negative (bit a of k = axis a); put back in (min, max) order it holds ...
+        f = c[:n, :6].view(np.float32)
+        for a in range(3):
+            lo, hi = f[:, 2 * a].copy(), f[:, 2 * a + 1].copy()
+            assert ((lo >= hi) if (k >> a) & 1 else (lo <= hi)).all()
+            if (k >> a) & 1:
+                f[:, 2 * a], f[:, 2 * a + 1] = hi, lo
+        # ... the same set of (box, leaf run) pairs, plus the closing entry
         assert {tuple(e[:6]) + (e[7],) for e in c[:n]} == plain
         last = c[n]
         assert np.isinf(last[:2].view(np.float32)).all() and last[6] == total and last[7] == NONE
