@@ -803,6 +803,8 @@ int rt_upload_scene(rt_context* ctx, rt_scene* s) {
         d.far_trigger2 = (sc.flat.far_spheres + sc.flat.far_tris) == 0 ? std::numeric_limits<float>::infinity()
                                                                         : (float)(reach > 0 ? reach * reach * 0.9999 : 0.0);
     }
+    // the kernels address a search-structure entry by a 32-bit byte offset (32 bytes per entry)
+    if (d.n_fast_nodes >= (1 << 27)) return fail(RT_ERR_LIMIT, "search structure beyond 2^27 entries");
     ctx->huge_coords = hugeCoords;
     d.n_spheres = (int)sc.spheres.size();
     d.n_tris = (int)sc.triangles.size();

@@ -1091,7 +1091,11 @@ __global__ void __launch_bounds__(WF_MAX_THREADS, LDS ? WF_WAVES_LDS : WF_WAVES_
                                 schedLanes[5] += popc64(__ballot(op == OP_BOX));
                             }
                             if (op == OP_BOX) {
-                                const float4 n0 = sv.fnodes[2 * idx], n1 = sv.fnodes[2 * idx + 1];
+                                // entry idx at a 32-bit byte offset from the (uniform) table address: the load then
+                                // takes "scalar base + vector offset" and no 64-bit address is formed per lane
+                                // (entries are limited to 2^27 by the upload)
+                                const float4* e = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(sv.fnodes) + ((uint32_t)idx << 5));
+                                const float4 n0 = e[0], n1 = e[1];
                                 const int first = (int)fbits(n1.w);
                                 if (COUNT) st.v[C_NODE]++;
                                 const bool pass = decltype(sortedPlanes)::value
