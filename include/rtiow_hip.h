@@ -239,7 +239,8 @@ int rt_last_build_ms(rt_context* ctx, float* ms);
 int rt_read_search_structure(rt_context* ctx, int* n_entries, uint32_t* entries8, int* n_refs, uint32_t* refs);
 
 /* Copies the flattened scene, camera and background to the device (replaces what
- * `Raytracer`'s constructor captures from Scene&, Raytracer.h:27-31). */
+ * `Raytracer`'s constructor captures from Scene&, Raytracer.h:27-31).  Returns RT_ERR_LIMIT if the search
+ * structure has 2^27 entries or more (the kernels address its entries by 32-bit byte offsets). */
 int rt_upload_scene(rt_context* ctx, rt_scene* s);
 
 /* Image size and the share of it this context renders.  The image is cut into 8x8-pixel
