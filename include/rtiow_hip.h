@@ -156,6 +156,13 @@ int rt_scene_set_camera(rt_scene* s, const float* lookfrom3, const float* lookat
  * (R/src/RaytracingApplication.cpp:140-147): origin, lowerLeftCorner, horizontal, vertical,
  * u, v, w (3 floats each), lensRadius. */
 int rt_scene_get_camera(const rt_scene* s, float* out22);
+/* The same eight members handed over as they are, in that order: what `Raytracer`'s constructor copies out
+ * of Scene& (`mCamera = scene.camera`, R/src/Core/Raytracer.h:28; the members are R/src/Core/Camera.h:35-38)
+ * and what the GPU toggle uploads as uniforms (R/src/RaytracingApplication.cpp:140-147).  A caller that
+ * holds a constructed Camera has only these -- the constructor's arguments are gone, and recovering them
+ * would go through atan/tan and not round-trip -- so the renderer takes them bit for bit:
+ * rt_scene_get_camera() returns exactly what was set.  No value is checked or normalised. */
+int rt_scene_set_camera_members(rt_scene* s, const float* in22);
 int rt_scene_set_background(rt_scene* s, float r, float g, float b); /* Scene::background */
 /* Normal mapping for PBR materials that carry a normal map.  Off (default): as the reference renders,
  * whose PBRMaterial::scatter forms the mapped normal and then overwrites it with rec.normal
@@ -251,6 +258,11 @@ int rt_set_target(rt_context* ctx, int width, int height, int rank, int world);
  * (256-byte aligned), e.g. a tensor that a collective library will read.  Not zeroed. */
 int rt_set_target_external(rt_context* ctx, int width, int height, int rank, int world, void* device_accum);
 size_t rt_accum_bytes(int width, int height, int world);
+/* Gives the accumulation buffer up (the end of mOrigColorData's life, R/src/Core/Raytracer.h:38): waits for
+ * the stream, frees a buffer the context allocated, forgets a caller-owned one.  Afterwards rt_render(),
+ * rt_clear() and the read calls fail with RT_ERR_STATE until the next rt_set_target().  For callers that
+ * are about to free an external buffer. */
+int rt_release_target(rt_context* ctx);
 
 /* Zeroes the accumulation buffer (the memset of Raytracer.h:30). */
 int rt_clear(rt_context* ctx);
@@ -260,7 +272,7 @@ int rt_clear(rt_context* ctx);
  * (R/src/Core/Raytracer.cpp:46-132) with rayColor (Raytracer.cpp:3-20) for each sample.
  * Random numbers are the reference shader's stateless hash keyed (x, y, sample, counter)
  * (R/assets/shaders/raytracer.comp:35-54).  Every sample's radiance passes through a device
- * colour buffer (16 bytes per pixel sample of the launch, allocated on first use and grown on
+ * colour buffer (12 bytes per pixel sample of the launch, allocated on first use and grown on
  * demand; calls that would need more than RT_COLORS_MB megabytes, default 4096, run as several
  * launches) and is added per pixel in sample order, so the sums have the bits of the reference's
  * sequential `pixelColor +=`.  Asynchronous on the context's stream unless the buffer must grow. */
@@ -271,7 +283,7 @@ int rt_render(rt_context* ctx, int first_sample, int n_samples, int max_depth);
  * array inside the library (64 MiB + 256 bytes per GPU in use, held until the process ends), so the
  * call allocates and frees nothing; a sample range that needs more colour space than that runs as
  * several launches.  Fails with RT_ERR_LIMIT when the context's share of the frame has more than
- * rt_noalloc_max_pixels() pixel slots (4,194,304: one sample of every slot must fit).  Every call on
+ * rt_noalloc_max_pixels() pixel slots (5,592,405 = 64 MiB / 12 bytes: one sample of every slot must fit).  Every call on
  * one GPU uses that GPU's array: calls that overlap in time on one GPU (other contexts, other
  * streams) race and must be serialised by the caller. */
 int rt_render_noalloc(rt_context* ctx, int first_sample, int n_samples, int max_depth);

@@ -74,6 +74,7 @@ SYMBOLS = {
     "rt_scene_wrap_bvh": (_I, [_VP]),
     "rt_scene_set_camera": (_I, [_VP, _VP, _VP, _VP, _F, _F, _F, _F]),
     "rt_scene_get_camera": (_I, [_VP, _VP]),
+    "rt_scene_set_camera_members": (_I, [_VP, _VP]),
     "rt_scene_set_background": (_I, [_VP, _F, _F, _F]),
     "rt_scene_set_normal_mapping": (_I, [_VP, _I]),
     "rt_scene_flatten": (_I, [_VP, C.POINTER(FlatInfo)]),
@@ -92,6 +93,7 @@ SYMBOLS = {
     "rt_set_target": (_I, [_VP, _I, _I, _I, _I]),
     "rt_set_target_external": (_I, [_VP, _I, _I, _I, _I, _VP]),
     "rt_accum_bytes": (C.c_size_t, [_I, _I, _I]),
+    "rt_release_target": (_I, [_VP]),
     "rt_clear": (_I, [_VP]),
     "rt_render": (_I, [_VP, _I, _I, _I]),
     "rt_render_noalloc": (_I, [_VP, _I, _I, _I]),
@@ -261,6 +263,12 @@ class Scene:
         _check(lib.rt_scene_get_camera(self.h, _p(out)))
         return out
 
+    def set_camera_members(self, members22):
+        """The eight derived Camera members as they are (origin, lowerLeftCorner, horizontal, vertical, u, v, w,
+        lensRadius: 22 floats), bit for bit."""
+        m = _f32(members22, 22)
+        _check(lib.rt_scene_set_camera_members(self.h, _p(m)))
+
     def set_background(self, rgb):
         _check(lib.rt_scene_set_background(self.h, rgb[0], rgb[1], rgb[2]))
 
@@ -385,6 +393,10 @@ class Context:
         else:
             _check(lib.rt_set_target_external(self.h, width, height, rank, world, C.c_void_p(external_ptr)))
         self.width, self.height, self.world = width, height, world
+
+    def release_target(self):
+        _check(lib.rt_release_target(self.h))
+        self.width = self.height = 0
 
     def clear(self):
         _check(lib.rt_clear(self.h))

@@ -359,6 +359,7 @@ bool decodeJpeg(const uint8_t* data, size_t n, Image* img, std::string* err) {
             if (len >= 14 && std::memcmp(seg, "Adobe\0", 6) == 0) adobeTransform = seg[11];
         } else if (m == 0xDA) {  // scan
             if (!haveFrame) return fail("scan before frame header");
+            if (len < 3) return fail("bad scan header");  // seg[0] lies inside the segment from here on
             const int ns = seg[0];
             if (ns < 1 || ns > nComp || len != 6 + 2 * ns) return fail("bad scan header");
             int order[3];
@@ -566,6 +567,11 @@ bool inflateZlib(const std::vector<uint8_t>& z, std::vector<uint8_t>* out, size_
     BitsLsb b{z.data() + 2, z.data() + z.size()};
     out->clear();
     out->reserve(expect);
+    // A few bytes of deflate data can expand a thousandfold: output is cut off at twice what the image header
+    // announces (plus one window), long before it can exhaust memory.  (stb_image inflates whatever the stream
+    // holds and ignores the surplus; files that far off their own header are refused here instead.)
+    const size_t ceiling = 2 * expect + 65536;
+    auto tooMuch = [&]() { return out->size() > ceiling; };
     static const uint16_t lenBase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
     static const uint8_t lenExtra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
     static const uint16_t distBase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
@@ -583,6 +589,7 @@ bool inflateZlib(const std::vector<uint8_t>& z, std::vector<uint8_t>* out, size_
             if (b.p + len > b.end) return fail("truncated stored block");
             out->insert(out->end(), b.p, b.p + len);
             b.p += len;
+            if (tooMuch()) return fail("far more image data than the header announces");
         } else if (type == 1 || type == 2) {
             DeflateCode lit, dist;
             uint8_t lengths[320];
@@ -638,6 +645,7 @@ bool inflateZlib(const std::vector<uint8_t>& z, std::vector<uint8_t>* out, size_
                     if (!b.ok || d > out->size()) return fail("corrupt compressed data");
                     const size_t start = out->size() - d;
                     for (int i = 0; i < len; i++) out->push_back((*out)[start + (size_t)i]);
+                    if (tooMuch()) return fail("far more image data than the header announces");
                 }
             }
         } else {

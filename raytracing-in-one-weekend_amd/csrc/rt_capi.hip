@@ -421,6 +421,14 @@ int rt_scene_get_camera(const rt_scene* s, float* out22) {
     std::memcpy(out22, &s->sc.camera, sizeof(float) * 22);
     return RT_OK;
 }
+int rt_scene_set_camera_members(rt_scene* s, const float* in22) {
+    if (!s || !in22) return fail(RT_ERR_INVALID, "bad arguments");
+    // the search structure orders its entries by distance from the eye: a moved eye makes it stale
+    // (still correct, only slower), and the next flatten() rebuilds it
+    if (std::memcmp(in22, s->sc.camera.origin, sizeof(float) * 3) != 0) s->sc.flat.fast_stale = true;
+    std::memcpy(&s->sc.camera, in22, sizeof(float) * 22);
+    return RT_OK;
+}
 int rt_scene_set_normal_mapping(rt_scene* s, int on) {
     if (!s) return fail(RT_ERR_INVALID, "null scene");
     s->sc.normal_mapping = on != 0;
@@ -869,6 +877,16 @@ int rt_set_target_external(rt_context* ctx, int width, int height, int rank, int
     return setTarget(ctx, width, height, rank, world, device_accum);
 }
 
+int rt_release_target(rt_context* ctx) {
+    if (!ctx) return fail(RT_ERR_INVALID, "null context");
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    freeTarget(ctx);
+    ctx->width = ctx->height = 0;
+    ctx->n_local_tiles = 0;
+    return RT_OK;
+}
+
 int rt_clear(rt_context* ctx) {
     if (!ctx || !ctx->accum) return fail(RT_ERR_STATE, "rt_set_target() has not been called");
     HIP_TRY(hipSetDevice(ctx->device));
@@ -893,7 +911,7 @@ int rt_render(rt_context* ctx, int first_sample, int n_samples, int max_depth) {
     return RT_OK;
 }
 
-size_t rt_noalloc_max_pixels(void) { return kScratchColorBytes / 16; }
+size_t rt_noalloc_max_pixels(void) { return kScratchColorBytes / sizeof(rt::Radiance); }
 
 int rt_render_noalloc(rt_context* ctx, int first_sample, int n_samples, int max_depth) {
     int rc = checkRenderState(ctx);
@@ -905,7 +923,7 @@ int rt_render_noalloc(rt_context* ctx, int first_sample, int n_samples, int max_
     HIP_TRY(hipSetDevice(ctx->device));
     unsigned char* base = g_scratchPtr[ctx->device];
     if (!base) return fail(RT_ERR_STATE, "the scratch array of this device was never looked up");
-    Workspace ws{reinterpret_cast<rt::Radiance*>(base + kScratchQueueBytes), kScratchColorBytes / 16,
+    Workspace ws{reinterpret_cast<rt::Radiance*>(base + kScratchQueueBytes), kScratchColorBytes / sizeof(rt::Radiance),
                  reinterpret_cast<unsigned int*>(base)};
     rt::RenderArgs a = makeArgs(ctx, first_sample, n_samples, max_depth);
     HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));

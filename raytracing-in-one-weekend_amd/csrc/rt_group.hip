@@ -158,19 +158,40 @@ int rt_group_upload_scene(rt_group* g, rt_scene* s) {
     return RT_OK;
 }
 
+// On failure the group is left WITHOUT a target: every context is detached from its (freed) payload, so a
+// later render, clear or read fails with RT_ERR_STATE instead of touching freed device memory.
+static int dropTargets(rt_group* g, int rc) {
+    const std::string keep = g_groupErr;
+    for (rt_context* c : g->ctx) (void)rt_release_target(c);
+    freeTargets(g);
+    g->width = g->height = 0;
+    g_groupErr = keep;
+    return rc;
+}
+
 int rt_group_set_target(rt_group* g, int width, int height) {
     if (!g) return gfail(RT_ERR_INVALID, "null group");
     const int n = (int)g->ctx.size();
+    // everything rt_set_target_external() would refuse is refused here, before the old target is given up
+    if (width < 2 || height < 2) return gfail(RT_ERR_INVALID, "image must be at least 2x2 (the pixel map divides by W-1, H-1)");
+    if ((long long)width * height > (1ll << 30)) return gfail(RT_ERR_LIMIT, "image beyond 2^30 pixels");
     const size_t bytes = rt_accum_bytes(width, height, n);
     if (bytes == 0) return gfail(RT_ERR_INVALID, "bad image size");
     for (rt_context* c : g->ctx) GROUP_TRY_RT(rt_sync(c));
+    for (rt_context* c : g->ctx) (void)rt_release_target(c);  // the contexts let go of the payloads before they are freed
     freeTargets(g);
+    g->width = g->height = 0;
     for (int i = 0; i < n; i++) {
-        GROUP_TRY_HIP(hipSetDevice(g->devices[(size_t)i]));
-        GROUP_TRY_HIP(hipMalloc(&g->payload[(size_t)i], bytes));
-        GROUP_TRY_HIP(hipMalloc(&g->gathered[(size_t)i], bytes * (size_t)n));
-        GROUP_TRY_RT(rt_set_target_external(g->ctx[(size_t)i], width, height, i, n, g->payload[(size_t)i]));
-        GROUP_TRY_RT(rt_clear(g->ctx[(size_t)i]));
+        hipError_t e = hipSetDevice(g->devices[(size_t)i]);
+        if (e == hipSuccess) e = hipMalloc(&g->payload[(size_t)i], bytes);
+        if (e == hipSuccess) e = hipMalloc(&g->gathered[(size_t)i], bytes * (size_t)n);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            return dropTargets(g, gfail(RT_ERR_HIP, std::string("target allocation: ") + hipGetErrorString(e)));
+        }
+        int rc = rt_set_target_external(g->ctx[(size_t)i], width, height, i, n, g->payload[(size_t)i]);
+        if (rc == RT_OK) rc = rt_clear(g->ctx[(size_t)i]);
+        if (rc < 0) return dropTargets(g, gfail(rc, rt_last_error()));
     }
     g->width = width;
     g->height = height;
@@ -179,12 +200,14 @@ int rt_group_set_target(rt_group* g, int width, int height) {
 
 int rt_group_clear(rt_group* g) {
     if (!g) return gfail(RT_ERR_INVALID, "null group");
+    if (g->width == 0) return gfail(RT_ERR_STATE, "rt_group_set_target() has not been called");
     for (rt_context* c : g->ctx) GROUP_TRY_RT(rt_clear(c));
     return RT_OK;
 }
 
 int rt_group_render(rt_group* g, int first_sample, int n_samples, int max_depth) {
     if (!g) return gfail(RT_ERR_INVALID, "null group");
+    if (g->width == 0) return gfail(RT_ERR_STATE, "rt_group_set_target() has not been called");
     // asynchronous on every device's stream: the devices render their tiles side by side
     for (rt_context* c : g->ctx) GROUP_TRY_RT(rt_render(c, first_sample, n_samples, max_depth));
     return RT_OK;

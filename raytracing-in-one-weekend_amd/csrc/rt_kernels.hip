@@ -1344,7 +1344,13 @@ __global__ void __launch_bounds__(256) accumulateColors(RenderArgs a) {
     if (base < 0) base += a.world;
     const int tx = base + k * a.world;
     const int px = tx * kTile + (l & 7), py = ty * kTile + (l >> 3);
-    if (!(tx < a.tiles_x && px < a.width && py < a.height)) return;
+    if (!(tx < a.tiles_x && px < a.width && py < a.height)) {
+        // a slot outside the image holds no colour, but it does carry the sample count like every other slot
+        // (the first slot of a rank's buffer is where the host reads it, and on a narrow frame shared by many
+        // ranks that slot can lie outside the image)
+        a.accum[q] = make_float4(0.0f, 0.0f, 0.0f, (float)(a.first_sample + a.n_samples));
+        return;
+    }
     const float4 acc = a.accum[q];
     V3 sum{acc.x, acc.y, acc.z};
     for (int s = 0; s < a.n_samples; s++) {

@@ -323,7 +323,7 @@ def test_colour_buffer_budget_cuts_launches_without_changing_bits(rt, scenes, gp
     scenes.cover_scene(a, w, h)
     gpu_ctx.upload_scene(a)
     whole = render_gpu(gpu_ctx, w, h, 0, spp)
-    monkeypatch.setenv("RT_COLORS_MB", "16")     # 16 MB / (22,400 pixel slots x 16 B) = 46 samples per launch
+    monkeypatch.setenv("RT_COLORS_MB", "16")     # 16 MB / (22,400 pixel slots x 12 B) = 62 samples per launch
     cut = render_gpu(gpu_ctx, w, h, 0, spp)
     assert np.array_equal(bits(cut), bits(whole))
 
@@ -598,6 +598,27 @@ def test_cancel_stops_a_long_single_pass(rt, scenes, gpu_ctx):
     gpu_ctx.run(2, 1, 50)               # cleared again
 
 
+def test_every_slot_carries_the_sample_count(rt, scenes, tiling, gpu_ctx):
+    """A narrow frame shared by many ranks: the first slot of rank 5 of 8 at width 32 lies outside the image
+    (its tile column would be 5 of 4), and that slot is where the host reads how many samples a cancelled
+    run completed.  Every slot, inside the image or not, holds the count."""
+    import torch
+    w, h, world, rank = 32, 24, 8, 5
+    a = rt.Scene()
+    scenes.cover_scene(a, w, h)
+    gpu_ctx.upload_scene(a)
+    n4 = tiling.payload_float4s(w, h, world)
+    buf = torch.zeros(n4, 4, dtype=torch.float32, device="cuda:0")
+    gpu_ctx.set_target(w, h, rank, world, external_ptr=buf.data_ptr())
+    gpu_ctx.render(0, 3, 50)
+    gpu_ctx.render(3, 2, 50)
+    gpu_ctx.sync()
+    got = buf.cpu().numpy()
+    assert (got[:, 3] == 5.0).all()
+    assert got[:, :3].any()
+    gpu_ctx.release_target()
+
+
 def test_ingested_tree_renders_like_the_built_one(rt, orc, scenes, gpu_ctx):
     """A scene whose BVH was handed in node by node (rt_scene_begin_bvh_node ...) renders the same bits
     as the scene whose BVH the library built, which in turn equals the oracle."""
@@ -640,6 +661,33 @@ def test_device_group_of_one_gathers_over_rccl(rt, scenes, gpu_ctx):
     g.set_target(64, 36)              # re-targeting frees and re-creates the per-device buffers
     g.render(0, 1, 50)
     assert g.read_accum()[..., :3].max() > 0
+    # a refused size leaves the old target in place ...
+    with pytest.raises(rt.RtError) as e:
+        g.set_target(1, 1)
+    assert e.value.code == -1
+    g.render(1, 1, 50)
+    assert g.read_accum()[..., :3].max() > 0
     g.close()
     with pytest.raises(rt.RtError):
         rt.Group([99])                # no such device
+
+
+def test_released_target_is_refused_not_dereferenced(rt, scenes, gpu_ctx):
+    """rt_release_target(): render, clear and the read calls report RT_ERR_STATE afterwards (this is what the
+    device group does to its contexts before it frees their payloads)."""
+    a = rt.Scene()
+    scenes.cover_scene(a, 64, 36)
+    gpu_ctx.upload_scene(a)
+    gpu_ctx.set_target(64, 36)
+    gpu_ctx.render(0, 1, 50)
+    gpu_ctx.sync()
+    gpu_ctx.release_target()
+    for call in (lambda: gpu_ctx.render(0, 1, 50), gpu_ctx.clear):
+        with pytest.raises(rt.RtError) as e:
+            call()
+        assert e.value.code == -4
+    assert rt.lib.rt_read_rgba8(gpu_ctx.h, 1, None) < 0
+    gpu_ctx.set_target(64, 36)
+    gpu_ctx.render(0, 1, 50)
+    gpu_ctx.sync()
+    assert gpu_ctx.read_accum()[..., :3].max() > 0

@@ -73,3 +73,34 @@ def test_the_unedited_vase_still_loads(rt):
     s = rt.Scene()
     first = s.add_mesh_gltf(rt.IDENTITY, os.path.join(VASE, "brass_vase_04_4k.gltf"), s.add_material(0, (0.5, 0.5, 0.5)))
     assert first == 0 and s.flatten().n_triangles == 2760
+
+
+def test_jpeg_that_ends_inside_its_scan_header_is_refused(rt):
+    """A file whose last bytes are FF DA 00 02 (a scan segment of length 2, i.e. no header bytes at all) after a
+    valid frame header: the component count of the scan must not be read past the end of the buffer."""
+    names = sorted(n for n in os.listdir(os.path.join(HERE, "golden", "images")) if n.endswith(".jpg") and "progressive" not in n)
+    src = open(os.path.join(HERE, "golden", "images", names[0]), "rb").read()
+    sos = src.index(b"\xff\xda")
+    bad = src[:sos] + b"\xff\xda\x00\x02"
+    with pytest.raises(rt.RtError) as e:
+        rt.image_decode(bad)
+    assert e.value.code == -1
+
+
+def test_png_whose_data_inflates_far_beyond_its_header_is_refused(rt):
+    """A 1x1 PNG with 8 MB of zeros in its IDAT (8 KB compressed): inflate stops at about twice the size the
+    header announces instead of expanding whatever the stream holds."""
+    import struct
+    import zlib
+
+    def chunk(kind, data):
+        return struct.pack(">I", len(data)) + kind + data + struct.pack(">I", zlib.crc32(kind + data) & 0xFFFFFFFF)
+    png = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 1, 1, 8, 0, 0, 0, 0)) \
+        + chunk(b"IDAT", zlib.compress(b"\x00" * (8 << 20), 9)) + chunk(b"IEND", b"")
+    with pytest.raises(rt.RtError) as e:
+        rt.image_decode(png)
+    assert e.value.code == -1 and "more image data" in str(e.value)
+    # the same image with exactly its two bytes of data decodes
+    ok = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 1, 1, 8, 0, 0, 0, 0)) \
+        + chunk(b"IDAT", zlib.compress(b"\x00\x7f")) + chunk(b"IEND", b"")
+    assert rt.image_decode(ok).tolist() == [[[0x7f]]]

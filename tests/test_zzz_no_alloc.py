@@ -43,7 +43,7 @@ def test_noalloc_render_equals_render(rt, scenes, gpu_ctx):
 
 
 def test_noalloc_cuts_long_sample_ranges_and_refuses_oversized_frames(rt, scenes, gpu_ctx):
-    # 1920x1080 has 2,073,600 pixel slots: 33 MB of colours per sample, so 64 MiB holds two samples
+    # 1920x1080 has 2,073,600 pixel slots: 24.9 MB of colours per sample (12 bytes each), so 64 MiB holds two samples
     # per launch and five samples run as three launches
     w, h, spp = 1920, 1080, 5
     a = rt.Scene()
@@ -58,7 +58,7 @@ def test_noalloc_cuts_long_sample_ranges_and_refuses_oversized_frames(rt, scenes
     gpu_ctx.sync()
     assert np.array_equal(bits(gpu_ctx.read_accum()), bits(want))
     # 3840x2160 = 8.3 M slots > rt_noalloc_max_pixels(): refused, nothing rendered
-    assert rt.lib.rt_noalloc_max_pixels() == (64 << 20) // 16
+    assert rt.lib.rt_noalloc_max_pixels() == (64 << 20) // 12
     gpu_ctx.set_target(3840, 2160)
     with pytest.raises(rt.RtError) as e:
         gpu_ctx.render_noalloc(0, 1, 50)
