@@ -23,6 +23,7 @@
 namespace rt {
 hipError_t launchRender(const RenderArgs& a, bool lds, bool count, int blocks, int threads, hipStream_t stream);
 hipError_t launchWavefront(const RenderArgs& a, bool lds, bool count, int blocks, int threads, hipStream_t stream);
+hipError_t launchTwoPass(const RenderArgs& a, bool count, int blocks, int threads, hipStream_t stream);
 hipError_t launchTrace(const DevScene& sc, int n, const float* rays, int* kind, int* id, float* t, float* normal,
                        int* front, float* uv, hipStream_t stream);
 hipError_t launchScatter(const DevScene& sc, int n, const int* mat, const float* rayIn, const float* p, const float* nrm,
@@ -69,6 +70,8 @@ struct rt_context {
     unsigned long long sched_stats[14] = {0};  // from the last rt_count(): {executions, lanes} per operation
     rt::Radiance* colors = nullptr;  // per-sample radiance of the split mode (grown on demand)
     size_t colors_cap = 0;           // in samples
+    float4* records = nullptr;       // path records of the two-pass launches, three planes of records_cap (grown on demand)
+    size_t records_cap = 0;          // in samples
     bool device_build = false;  // rt_upload_scene() builds the search structure on the device
     float build_ms = 0.0f;      // device time of the last such build
     void* resolved = nullptr;  // row-major image the read-out calls resolve into (grown on demand, kept)
@@ -79,7 +82,7 @@ struct rt_context {
 // buffer of one launch.  One copy per GPU the library runs on, held until the process ends.  The
 // name is a host-side stand-in, never a device address: host code uses the per-device pointer
 // that rt_create() obtains with hipGetSymbolAddress().
-constexpr size_t kScratchQueueBytes = 256;
+constexpr size_t kScratchQueueBytes = rt::kQueueBytes;
 constexpr size_t kScratchColorBytes = size_t(RT_NOALLOC_SCRATCH_MB) << 20;
 static __device__ __align__(256) unsigned char scratch[kScratchQueueBytes + kScratchColorBytes];
 
@@ -228,6 +231,13 @@ int launch(rt_context* ctx, rt::RenderArgs& a, bool count, const Workspace* fixe
                                           std::to_string(fixed->colors_cap) + " slots");
         budget = std::min(budget, fixed->colors_cap * sizeof(rt::Radiance));
     }
+    // Two passes (primaryPass, then the loop over its path records) when the tables are in LDS: the camera rays
+    // of a tile are walked together, a full wave at a time.  Not for the fixed-scratch entry point (the records
+    // need 48 bytes per pixel sample of a launch; RT_RECORDS_MB, default 6400, bounds them), not with the
+    // reference-order walk forced, and not for the diagnostic timing launches.
+    const bool twoPass = !fixed && ctx->use_lds && !a.sc.force_ref && a.max_depth >= 1 && !a.timing && envInt("RT_TWO_PASS", 1) != 0;
+    constexpr size_t kRecordBytes = 48;
+    if (twoPass) budget = std::min(budget, ((size_t)std::max(16, envInt("RT_RECORDS_MB", 6400)) << 20) / kRecordBytes * sizeof(rt::Radiance));
     size_t maxSamples = std::max<size_t>(1, budget / ((size_t)nSlots * sizeof(rt::Radiance)));
     maxSamples = std::min<size_t>(maxSamples, (size_t)((1ll << 31) / nSlots));
     maxSamples = std::max<size_t>(1, std::min<size_t>(maxSamples, (size_t)a.n_samples));
@@ -243,15 +253,32 @@ int launch(rt_context* ctx, rt::RenderArgs& a, bool count, const Workspace* fixe
             HIP_TRY(hipMalloc((void**)&ctx->colors, need * sizeof(rt::Radiance)));
             ctx->colors_cap = need;
         }
+        if (twoPass && need > ctx->records_cap) {
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            if (ctx->records) (void)hipFree(ctx->records);
+            ctx->records = nullptr;
+            ctx->records_cap = 0;
+            // + one byte per chunk of 64 for the record counts, read a dword at a time
+            HIP_TRY(hipMalloc((void**)&ctx->records, need * kRecordBytes + need / 64 + 16));
+            ctx->records_cap = need;
+        }
         a.first_sample = first + s0;
         a.n_samples = ns;
         a.colors = fixed ? fixed->colors : ctx->colors;
+        a.records = ctx->records;
+        a.records_cap = (unsigned int)ctx->records_cap;
+        a.record_counts = reinterpret_cast<uint8_t*>(ctx->records) + ctx->records_cap * kRecordBytes;
+        a.chunk_group = std::max(1, std::min(64, envInt("RT_CHUNK_GROUP", 1)));
+        a.n_queues = std::max(1, std::min(rt::kMaxQueues, envInt("RT_QUEUES", 16)));
         int blocks = maxBlocks;
         const long long needed = ((long long)a.n_local_tiles * ns + wfWaves - 1) / wfWaves;
         if (blocks > needed) blocks = (int)needed;
         if (blocks < 1) blocks = 1;
-        HIP_TRY(hipMemsetAsync(a.queue, 0, 256, ctx->stream));
-        HIP_TRY(rt::launchWavefront(a, ctx->use_lds, count, blocks, wfThreads, ctx->stream));
+        HIP_TRY(hipMemsetAsync(a.queue, 0, rt::kQueueBytes, ctx->stream));
+        if (twoPass)
+            HIP_TRY(rt::launchTwoPass(a, count, blocks, wfThreads, ctx->stream));
+        else
+            HIP_TRY(rt::launchWavefront(a, ctx->use_lds, count, blocks, wfThreads, ctx->stream));
     }
     return RT_OK;
 }
@@ -554,7 +581,7 @@ int rt_create(int device, rt_context** out) {
     ctx->stream = ctx->own_stream;
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
-    if (e == hipSuccess) e = hipMalloc((void**)&ctx->queue, 256);
+    if (e == hipSuccess) e = hipMalloc((void**)&ctx->queue, rt::kQueueBytes);
     if (e == hipSuccess) e = hipMalloc((void**)&ctx->counters, 256);
     if (e == hipSuccess) e = hipHostMalloc((void**)&ctx->cancel_host, sizeof(int), hipHostMallocMapped);
     if (e == hipSuccess) {
@@ -576,6 +603,7 @@ void rt_destroy(rt_context* ctx) {
     freeScene(ctx);
     freeTarget(ctx);
     if (ctx->colors) (void)hipFree(ctx->colors);
+    if (ctx->records) (void)hipFree(ctx->records);
     if (ctx->resolved) (void)hipFree(ctx->resolved);
     if (ctx->queue) (void)hipFree(ctx->queue);
     if (ctx->counters) (void)hipFree(ctx->counters);

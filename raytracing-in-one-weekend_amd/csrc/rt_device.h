@@ -53,7 +53,11 @@ struct Radiance {
 struct RenderArgs {
     DevScene sc;
     float4* accum;        // tiled: [local tile][lane] -> {r, g, b, samples}
-    unsigned int* queue;  // [0] next-chunk counter of the persistent launch shape, [1] set when the launch was cut short (may be null)
+    // Work queue of the persistent launch shape (may be null): kQueueBytes, cleared before every launch.
+    // [1] is set when the launch was cut short; the counters that deal out the work are n_queues dwords at
+    // [kQueueFirst + kQueueStride * q], each on a cache line of its own.
+    unsigned int* queue;
+    int n_queues;
     const int* cancel;    // host-pinned flag the persistent waves read when they fetch a chunk (null: not cancellable)
     unsigned long long* counters;  // path statistics (counting launches only)
     int width, height;
@@ -68,12 +72,27 @@ struct RenderArgs {
     // per-sample radiance of the launch: colors[(sample - first_sample) * n_slots + pixel slot],
     // added to the accumulation buffer in sample order by accumulateColors()
     Radiance* colors;
+    // Two-pass launches (primaryPass + the persistent loop): one record per path that goes on after its first ray,
+    // three planes of records_cap float4 each:
+    //   {origin.xyz, direction.x}, {direction.yz, throughput.xy}, {throughput.z, rng key, rng counter, unit | flag << 31}
+    // flag: the record holds the camera ray itself, to be traced again along the reference-order array.
+    // The records of chunk c (64 units = one tile x one sample) sit at the front of slots 64 c .. 64 c + 63, and
+    // record_counts[c] (one byte per chunk) says how many there are; the loop takes chunks four at a time, so
+    // that one dword of counts comes with every queue index.
+    float4* records;
+    unsigned int records_cap;
+    uint8_t* record_counts;
+    int chunk_group;  // single-pass launches: chunks handed out per queue access
 };
 
 // Megabytes of the fixed colour scratch behind rt_render_noalloc() (one copy per GPU in use).
 #ifndef RT_NOALLOC_SCRATCH_MB
 #define RT_NOALLOC_SCRATCH_MB 64
 #endif
+
+// layout of RenderArgs::queue, in dwords
+constexpr int kQueueFirst = 64, kQueueStride = 32, kMaxQueues = 30;
+constexpr size_t kQueueBytes = 4096;
 
 constexpr int kTile = 8;  // one wave64 = one 8x8 pixel tile
 

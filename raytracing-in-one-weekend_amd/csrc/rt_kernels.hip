@@ -863,9 +863,14 @@ __device__ __forceinline__ int popc64(unsigned long long m) {
 // TIME (diagnostic): instead of path counters, each wave adds up its clock ticks per operation
 // -- box bursts, primitive runs, SHADE, NEWPATH, reference-order box steps, and everything else
 // (votes, loop overhead) -- into the scheduling-statistics slots.
-template <bool LDS, bool COUNT, bool TIME = false, bool FULL = true, bool NMAP = false>
+// SPLIT: second pass of a two-pass launch.  primaryPass() has traced and shaded every path's camera ray a whole
+// tile at a time and left one record per path that goes on; NEWPATH then hands a lane the next record instead of
+// a pixel sample, and the queue counts chunks of 64 records.
+template <bool LDS, bool COUNT, bool TIME = false, bool FULL = true, bool NMAP = false, bool SPLIT = false>
 __global__ void __launch_bounds__(WF_MAX_THREADS, LDS ? WF_WAVES_LDS : WF_WAVES_GLOBAL) renderWavefront(RenderArgs a) {
     const DevScene& sc = a.sc;
+    // a first pass that was cut short has not written all its records: nothing to go on with
+    if (SPLIT && a.queue[1]) return;
     fillCounterLut();
     SceneView sv;
     if (LDS) {
@@ -882,6 +887,9 @@ __global__ void __launch_bounds__(WF_MAX_THREADS, LDS ? WF_WAVES_LDS : WF_WAVES_
     const float originLimit = sc.origin_limit;
     const int nTiles = a.n_local_tiles;
     const unsigned int nChunks = (unsigned int)nTiles * (unsigned int)a.n_samples;  // 64 units each
+    // the queue hands out groups of consecutive chunks (see fetchChunk)
+    const unsigned int groupSize = SPLIT ? 4u : (unsigned int)a.chunk_group;
+    const unsigned int nGroups = (nChunks + groupSize - 1u) / groupSize;
     const int boxKeep = a.knob[0];    // keep running BOX steps while at least this many lanes want one
     const int shadeMin = a.knob[1];   // run SHADE / NEWPATH early once this many lanes wait for it
     Stats st;
@@ -905,10 +913,14 @@ __global__ void __launch_bounds__(WF_MAX_THREADS, LDS ? WF_WAVES_LDS : WF_WAVES_
 
     // The wave's current chunk of the queue: 64 units = the 64 pixels of one tile for one sample.
     // chunkNext counts the lanes' worth already handed out (64 = used up), chunk < 0 = queue dry.
-    int chunk = 0, chunkNext = 64;
+    int chunk = 0, chunkNext = 64, chunkLive = 64;
+    int groupLeft = 0;  // chunks of the current group after this one
     int chunkSample = 0, chunkX0 = 0, chunkY0 = 0;
     bool chunkInside = false;
     unsigned int chunkAhead = 0;  // lane 0: the queue index fetched ahead of need
+    // SPLIT: the record counts (a byte per chunk, four chunks per group) travel one step behind the queue index:
+    // countsAhead (lane 0) belongs to group nextGroup, whose index the queue gave out one access earlier
+    unsigned int countsAhead = 0, nextGroup = 0, groupCounts = 0;
     // Raytracer::Cancel() (R/src/Core/Raytracer.h:59-62; the reference polls its flag once per scanline,
     // Raytracer.cpp:54,78,148,176).  The caller's flag lives in pinned host memory, and a read of it
     // crosses PCIe, so only the first wave of a workgroup reads it, on every 16th chunk it fetches, and
@@ -918,19 +930,48 @@ __global__ void __launch_bounds__(WF_MAX_THREADS, LDS ? WF_WAVES_LDS : WF_WAVES_
     // short, which makes accumulateColors() leave the image alone.
     const bool pollsHost = (threadIdx.x >> 6) == 0;
     unsigned int fetches = 15;  // the first fetch polls
+    // The queue is kNumQueues counters on cache lines of their own.  Atomics on ONE address retire at about 80 M/s
+    // on this machine whoever issues them, and a launch of 2 M chunks in 25 ms asks for exactly that: with one
+    // counter the 1080p 64-spp launch took 25.4 ms, with two chunks per access 20.3 ms, with this 19.x.
+    // Counter q deals out the groups q, q + Q, q + 2 Q, ...; a wave starts at the counter of its number and moves
+    // on to the next one when its own has run dry, so the last groups are still shared out one at a time.
+    const unsigned int nQueues = (unsigned int)a.n_queues;
+    unsigned int curQueue = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) % nQueues, queueMoves = 0;
+    constexpr unsigned int kCancelled = 0xFFFFFFFFu;
     auto fetchChunk = [&]() {
-        unsigned int c = atomicAdd(a.queue, 1u);
+        unsigned int c = atomicAdd(a.queue + kQueueFirst + kQueueStride * curQueue, 1u) * nQueues + curQueue;
+        if (c >= kCancelled) c = kCancelled - 1u;
         if (a.cancel) {
             if (pollsHost && (++fetches & 15u) == 0u &&
                 __hip_atomic_load(a.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM))
                 __hip_atomic_store(&g_cancelSeen, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (__hip_atomic_load(&g_cancelSeen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
                 a.queue[1] = 1u;
-                c = 0xFFFFFFFFu;
+                c = kCancelled;
             }
         }
         return c;
     };
+    // What lane 0 fetched, for the wave: a group, or "no more" (>= nGroups) once every counter has run dry (or the
+    // launch was cancelled).  A dry counter sends the wave to the next one, where it waits for the reply: that
+    // happens at most nQueues - 1 times per wave, at the end of the launch.
+    auto fetched = [&](unsigned int ahead) {
+        unsigned int g = __builtin_amdgcn_readfirstlane(ahead);
+        while (g >= nGroups && g != kCancelled && queueMoves + 1u < nQueues) {
+            queueMoves += 1u;
+            curQueue = curQueue + 1u == nQueues ? 0u : curQueue + 1u;
+            unsigned int t = 0;
+            if (lane == 0) t = fetchChunk();
+            g = __builtin_amdgcn_readfirstlane(t);
+        }
+        return g;
+    };
+    if (SPLIT) {
+        unsigned int g = 0;
+        if (lane == 0) g = fetchChunk();
+        nextGroup = fetched(g);
+        if (lane == 0) countsAhead = nextGroup < nGroups ? reinterpret_cast<const uint32_t*>(a.record_counts)[nextGroup] : 0u;
+    }
     if (lane == 0) chunkAhead = fetchChunk();
     unsigned long long schedExec[7] = {0, 0, 0, 0, 0, 0, 0}, schedLanes[7] = {0, 0, 0, 0, 0, 0, 0};
     // TIME: ticks per stretch of the loop (T_* below); tMark = last reading
@@ -1255,17 +1296,43 @@ __global__ void __launch_bounds__(WF_MAX_THREADS, LDS ? WF_WAVES_LDS : WF_WAVES_
             }
             lap(T_FINISH);
             const unsigned long long m = __ballot(want);
-            if (chunk >= 0 && chunkNext >= 64) {  // chunk used up: take the one fetched ahead
-                const unsigned int c = __builtin_amdgcn_readfirstlane(chunkAhead);
-                if (c >= nChunks) {
-                    chunk = -1;  // the queue is dry
+            // chunk used up: the next one of its group, or the first of the group fetched ahead (SPLIT: chunks that
+            // left no record are passed over)
+            while (chunk >= 0 && chunkNext >= chunkLive) {
+                chunkNext = 0;
+                if (groupLeft > 0) {
+                    groupLeft -= 1;
+                    chunk += 1;
+                    groupCounts >>= 8;
                 } else {
-                    // and fetch the one after it now: the atomic's round trip to L2 (thousands of
-                    // cycles) is over long before this wave needs the index
-                    if (lane == 0) chunkAhead = fetchChunk();
-                    chunk = (int)c;
-                    chunkNext = 0;
+                    unsigned int g;
+                    if (SPLIT) {
+                        g = nextGroup;
+                        groupCounts = __builtin_amdgcn_readfirstlane(countsAhead);
+                        nextGroup = fetched(chunkAhead);
+                        if (lane == 0 && g < nGroups) {
+                            countsAhead = nextGroup < nGroups ? reinterpret_cast<const uint32_t*>(a.record_counts)[nextGroup] : 0u;
+                            chunkAhead = fetchChunk();
+                        }
+                    } else {
+                        g = fetched(chunkAhead);
+                        // and fetch the one after it now: the atomic's round trip to L2 (thousands of
+                        // cycles) is over long before this wave needs the index
+                        if (lane == 0 && g < nGroups) chunkAhead = fetchChunk();
+                    }
+                    if (g >= nGroups) {
+                        chunk = -1;  // the queue is dry
+                        break;
+                    }
+                    chunk = (int)(g * groupSize);
+                    const unsigned int rest = nChunks - 1u - (unsigned int)chunk;
+                    groupLeft = (int)(rest < groupSize - 1u ? rest : groupSize - 1u);
+                }
+                if (SPLIT) {
+                    chunkLive = (int)(groupCounts & 0xFFu);
+                } else {
                     // chunk -> (sample, tile) -> the tile's corner pixel, all wave-uniform
+                    const unsigned int c = (unsigned int)chunk;
                     const int sIdx = (int)(c / (unsigned int)nTiles);
                     const int tile = (int)(c - (unsigned int)sIdx * (unsigned int)nTiles);
                     const int ty = tile / a.tiles_per_row_local;
@@ -1286,8 +1353,31 @@ __global__ void __launch_bounds__(WF_MAX_THREADS, LDS ? WF_WAVES_LDS : WF_WAVES_
             const int rankInMask =
                 __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
             const int l = chunkNext + rankInMask;  // pixel inside the tile
-            const int px = chunkX0 + (l & 7), py = chunkY0 + (l >> 3);
             if (want & (chunk < 0)) op = OP_DONE;
+            if (SPLIT) {
+                const unsigned int rec = (unsigned int)chunk * 64u + (unsigned int)l;
+                if (want & (chunk >= 0) & (l < chunkLive)) {
+                    const float4 q0 = a.records[rec], q1 = a.records[(size_t)a.records_cap + rec],
+                                 q2 = a.records[2 * (size_t)a.records_cap + rec];
+                    r.o = V3{q0.x, q0.y, q0.z};
+                    r.d = V3{q0.w, q1.x, q1.y};
+                    thr = V3{q1.z, q1.w, q2.x};
+                    rng.key = fbits(q2.y);
+                    rng.counter = fbits(q2.z);
+                    const uint32_t uw = fbits(q2.w);
+                    const int again = (int)(uw >> 31);  // the camera ray itself, to be traced in reference order
+                    unit = uw & 0x7FFFFFFFu;
+                    depth = a.max_depth - 1 + again;
+                    startRay();
+                    if (again) {
+                        idx = 0;
+                        op = OP_REFBOX;
+                        mode = 1;
+                        if (COUNT) st.v[C_RAYS]--;  // counted by the first pass
+                    }
+                }
+            } else {
+            const int px = chunkX0 + (l & 7), py = chunkY0 + (l >> 3);
             if (want & (chunk >= 0) & (l < 64) & chunkInside & (px < a.width) & (py < a.height)) {
                 unit = (unsigned int)chunk * 64u + (unsigned int)l;
                 rng.init((uint32_t)px, (uint32_t)py, chunkSample);
@@ -1304,6 +1394,7 @@ __global__ void __launch_bounds__(WF_MAX_THREADS, LDS ? WF_WAVES_LDS : WF_WAVES_
                 } else {
                     startRay();
                 }
+            }
             }
             chunkNext += popc64(m);
             lap(T_CAMERA);
@@ -1325,6 +1416,214 @@ __global__ void __launch_bounds__(WF_MAX_THREADS, LDS ? WF_WAVES_LDS : WF_WAVES_
             unsigned long long v = st.v[i];
             for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
             // the scheduler statistics sit between the 13 path counters and the fallback count
+            if (lane == 0 && v) atomicAdd(&a.counters[i < 13 ? i : 27], v);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// First pass of a two-pass launch: every path's camera ray, a whole tile at a time.
+//
+// The 64 camera rays of one 8x8 tile and one sample leave (nearly) the same point in (nearly) the same
+// direction, so a wave walks the search structure ONCE for all of them: the entry's address is wave-uniform (a
+// scalar), every lane tests the entry's box against its own ray, the wave descends when any lane's test
+// passes and takes the skip link when none does, and a leaf run's primitives are tested by the lanes whose
+// box test passed.  A lane therefore tests a superset of the entries its own walk would have visited, which
+// can only add candidates to an exact, order-independent closest-hit rule (smallest distance, ties by the
+// reference's visit order; see primAnyOrder): the winner is the one its own walk finds, and the guard test
+// vouches for it as in the loop.  All 64 lanes are busy in every step, where the loop's box steps run for
+// 24 of 64.
+// Then the hit is shaded (Raytracer::rayColor's first level, R/src/Core/Raytracer.cpp:3-20) with the
+// wave still whole, and the pass leaves
+//   * the path's radiance in colors[unit] if it ended (background, light, absorbed, depth used up), or
+//   * a record {scattered ray, throughput, random stream, unit} for the persistent loop
+//     (renderWavefront<SPLIT = true>) to go on with.
+// A camera ray whose answer cannot be vouched for (zero direction component, origin beyond the padding's
+// reach, NaN distance, failed guard test) is handed over as it is, flagged, and the loop traces it along the
+// reference-order array.  A chunk's records go to the front of the chunk's own 64 slots and their number into
+// record_counts[chunk]: no atomic is involved, and the loop may take them in any order, since a path's radiance
+// is a function of (pixel, sample) alone.
+// Requires the tables in LDS (walk entries) and max_depth >= 1.
+template <bool COUNT, bool FULL, bool NMAP>
+__global__ void __launch_bounds__(WF_MAX_THREADS, WF_WAVES_LDS) primaryPass(RenderArgs a) {
+    const DevScene& sc = a.sc;
+    fillCounterLut();
+    const SceneView sv = stageScene(sc, a.knob[2] != 0, true);
+    const int lane = threadIdx.x & 63;
+    const uint32_t walkBegin = ldsAddress(sv.wnodes);
+    const uint32_t walkEnd = walkBegin + (uint32_t)sc.n_fast_nodes * kWalkEntryBytes;
+    const int nTiles = a.n_local_tiles;
+    const unsigned int nChunks = (unsigned int)nTiles * (unsigned int)a.n_samples;
+    const float originLimit = sc.origin_limit;
+    Stats st;
+    if (COUNT)
+        for (int i = 0; i < kNumStats; i++) st.v[i] = 0;
+    unsigned long long stepExec = 0, stepLanes = 0;
+
+    // Chunks are dealt out in turn (the work per chunk is nearly the same everywhere, and a queue would cost an
+    // atomic per chunk).  Cancel flag: see renderWavefront; the workgroup's first wave reads it on every 16th of
+    // its chunks.
+    const int wavesPerBlock = blockDim.x >> 6;
+    const unsigned int nWaves = gridDim.x * (unsigned int)wavesPerBlock;
+    const bool pollsHost = (threadIdx.x >> 6) == 0;
+    unsigned int turns = 15;
+    for (unsigned int c = blockIdx.x * (unsigned int)wavesPerBlock + (threadIdx.x >> 6); c < nChunks; c += nWaves) {
+        if (a.cancel) {
+            if (pollsHost && (++turns & 15u) == 0u &&
+                __hip_atomic_load(a.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM))
+                __hip_atomic_store(&g_cancelSeen, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (__hip_atomic_load(&g_cancelSeen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                a.queue[1] = 1u;
+                break;
+            }
+        }
+        // chunk -> (sample, tile) -> pixel of this lane
+        const int sIdx = (int)(c / (unsigned int)nTiles);
+        const int tile = (int)(c - (unsigned int)sIdx * (unsigned int)nTiles);
+        const int ty = tile / a.tiles_per_row_local;
+        const int k = tile - ty * a.tiles_per_row_local;
+        int base = (a.rank - ty) % a.world;
+        if (base < 0) base += a.world;
+        const int tx = base + k * a.world;
+        const int px = tx * kTile + (lane & 7), py = ty * kTile + (lane >> 3);
+        const bool in = (tx < a.tiles_x) & (px < a.width) & (py < a.height);
+        if (__ballot(in) == 0) {
+            if (lane == 0) a.record_counts[c] = 0;
+            continue;
+        }
+        const unsigned int unit = c * 64u + (unsigned int)lane;
+
+        Rng rng{0u, 0u};
+        Ray r{{0.f, 0.f, 0.f}, {0.f, 0.f, 1.f}};
+        if (in) {
+            rng.init((uint32_t)px, (uint32_t)py, a.first_sample + sIdx);
+            if (COUNT) {
+                st.v[C_SAMPLES]++;
+                st.v[C_RAYS]++;
+            }
+            // u is drawn before v (R/src/Core/Raytracer.cpp:86-87)
+            const float u = ((float)px + rng.next()) / (float)(a.width - 1);
+            const float v = ((float)py + rng.next()) / (float)(a.height - 1);
+            r = cameraRay(sc, u, v, rng);
+        }
+        const float invx = 1.0f / r.d.x, invy = 1.0f / r.d.y, invz = 1.0f / r.d.z;
+        const float aa = dot(r.d, r.d);
+        const float nox = -(r.o.x * invx), noy = -(r.o.y * invy), noz = -(r.o.z * invz);
+        const bool usable = in && fastTestUsable(r.o, originLimit, invx, invy, invz, nox, noy, noz);
+        Hit h{__builtin_inff(), kNoHit, 0.f, 0.f};
+        bool bad = false;
+        if (__ballot(usable)) {
+            const float epad = farRayPad(sc, r.o);
+            const float ex = epad * fabsf(invx), ey = epad * fabsf(invy), ez = epad * fabsf(invz);
+            const f32x2 ax{nox - ex, nox + ex}, ay{noy - ey, noy + ey}, az{noz - ez, noz + ez};
+            const uint32_t sx = (fbits(invx) >> 29) & 4u, sy = (fbits(invy) >> 29) & 4u, sz = (fbits(invz) >> 29) & 4u;
+            uint32_t e = walkBegin;  // wave-uniform
+            while (e < walkEnd) {
+                typedef __attribute__((address_space(3))) const float* LdsFloats;
+                typedef __attribute__((address_space(3))) const uint32_t* LdsWord;
+                const LdsBytes eb = (LdsBytes)(uintptr_t)e;
+                const LdsFloats qx = (LdsFloats)(eb + sx), qy = (LdsFloats)(eb + 12 + sy), qz = (LdsFloats)(eb + 24 + sz);
+                const f32x2u bx{qx[0], qx[1]}, by{qy[0], qy[1]}, bz{qz[0], qz[1]};
+                const uint32_t w = __builtin_amdgcn_readfirstlane(*(LdsWord)(eb + 36));
+                const f32x2 tx2 = __builtin_elementwise_fma(f32x2{bx.x, bx.y}, f32x2{invx, invx}, ax);
+                const f32x2 ty2 = __builtin_elementwise_fma(f32x2{by.x, by.y}, f32x2{invy, invy}, ay);
+                const f32x2 tz2 = __builtin_elementwise_fma(f32x2{bz.x, bz.y}, f32x2{invz, invz}, az);
+                const float tn = fmaxf(fmaxf(tx2.x, ty2.x), fmaxf(tz2.x, kTMin));
+                const float tf = fminf(fminf(tx2.y, ty2.y), fminf(tz2.y, h.t));
+                const bool pass = usable & (tn <= tf);
+                const unsigned long long any = __ballot(pass);
+                if (COUNT) {
+                    if (usable) st.v[C_NODE]++;
+                    stepExec += 1;
+                    stepLanes += popc64(__ballot(usable));
+                }
+                if (any == 0) {
+                    e = w & 0xFFFFu;
+                    continue;
+                }
+                e += kWalkEntryBytes;
+                const uint32_t first = w >> 16;
+                if (first >= kWalkEnd) continue;  // no leaf run under this entry
+                uint32_t p = first, ref;
+                do {
+                    ref = __builtin_amdgcn_readfirstlane(sv.frefs[p]);
+                    p += 1;
+                    if (pass) {
+                        float t, u = 0.0f, v = 0.0f;
+                        if (primRoot<COUNT, FULL>(sv, ref, r, aa, __builtin_inff(), t, u, v, &st)) {
+                            if (t != t) {
+                                bad = true;
+                            } else if (h.ref == kNoHit || t < h.t ||
+                                       (t == h.t && refOrder<FULL>(sv, ref) > refOrder<FULL>(sv, h.ref))) {
+                                h.t = t;
+                                h.ref = ref & ~kRefLast;
+                                if (FULL) {
+                                    h.bu = u;
+                                    h.bv = v;
+                                }
+                            }
+                        }
+                    }
+                } while (!(ref & kRefLast));
+            }
+        }
+        // what becomes of the path: 0 = ended (colour written), 1 = goes on with the scattered ray, 2 = the camera
+        // ray is handed over to be traced in reference order
+        int fate = 0;
+        V3 thr{1.0f, 1.0f, 1.0f};
+        if (in) {
+            const bool hit = h.ref != kNoHit;
+            bool vouched = usable & !bad;
+            if (vouched & hit) vouched = guardsPass<COUNT, FULL>(sv, r, invx, invy, invz, h, &st);
+            if (!vouched) {
+                if (COUNT && usable) st.v[C_FALLBACK]++;
+                fate = 2;
+            } else if (!hit) {
+                if (COUNT) st.v[C_MISS]++;
+                const V3 cc = thr * V3{sc.bg[0], sc.bg[1], sc.bg[2]};
+                a.colors[unit] = Radiance{cc.x, cc.y, cc.z};
+            } else {
+                if (COUNT) st.v[C_HITS]++;
+                const Surface sf = surfaceAt<FULL>(sc, sv, r, h);
+                Ray out{r.o, r.d};
+                V3 atten{1.0f, 1.0f, 1.0f}, emit;
+                const bool alive = scatter<COUNT, FULL, NMAP>(sc, sv, r, sf, rng, out, atten, emit, &st);
+                int depth = a.max_depth;
+                if (alive) {
+                    thr = thr * atten;
+                    depth -= 1;
+                }
+                if (!alive | (depth <= 0)) {
+                    if (COUNT && alive) st.v[C_CUTOFF]++;
+                    const V3 cc = thr * emit;
+                    a.colors[unit] = Radiance{cc.x, cc.y, cc.z};
+                } else {
+                    fate = 1;
+                    r = out;
+                }
+            }
+        }
+        // the chunk's records go to the front of its 64 slots, in lane order
+        const unsigned long long keep = __ballot(fate != 0);
+        if (lane == 0) a.record_counts[c] = (uint8_t)popc64(keep);
+        if (fate != 0) {
+            const unsigned int at =
+                c * 64u + __builtin_amdgcn_mbcnt_hi((unsigned)(keep >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)keep, 0u));
+            const uint32_t uw = unit | (fate == 2 ? 0x80000000u : 0u);
+            a.records[at] = make_float4(r.o.x, r.o.y, r.o.z, r.d.x);
+            a.records[(size_t)a.records_cap + at] = make_float4(r.d.y, r.d.z, thr.x, thr.y);
+            a.records[2 * (size_t)a.records_cap + at] =
+                make_float4(thr.z, __uint_as_float(rng.key), __uint_as_float(rng.counter), __uint_as_float(uw));
+        }
+    }
+    if (COUNT && lane == 0) {  // the uniform steps count as box steps of the scheduling statistics
+        atomicAdd(&a.counters[13 + 2 * 5], stepExec);
+        atomicAdd(&a.counters[14 + 2 * 5], stepLanes);
+    }
+    if (COUNT) {
+        for (int i = 0; i < kNumStats; i++) {
+            unsigned long long v = st.v[i];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
             if (lane == 0 && v) atomicAdd(&a.counters[i < 13 ? i : 27], v);
         }
     }
@@ -1507,6 +1806,36 @@ hipError_t launchWavefront(const RenderArgs& a, bool lds, bool count, int blocks
                           : launchWavefrontT<true, false>(a, blocks, threads, shmem, stream);
     return count ? launchWavefrontT<false, true>(a, blocks, threads, 0, stream)
                  : launchWavefrontT<false, false>(a, blocks, threads, 0, stream);
+}
+
+// Two-pass launch (tables in LDS): primaryPass, the persistent loop over its records, the per-pixel sums.
+template <bool COUNT, bool FULL, bool NMAP>
+static hipError_t launchTwoPassT(const RenderArgs& a, int blocks, int threads, size_t shmem, hipStream_t stream) {
+    (void)hipGetLastError();  // an earlier, unrelated failure must not be reported as this launch's
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(primaryPass<COUNT, FULL, NMAP>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(renderWavefront<true, COUNT, false, FULL, NMAP, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    primaryPass<COUNT, FULL, NMAP><<<blocks, threads, shmem, stream>>>(a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    renderWavefront<true, COUNT, false, FULL, NMAP, true><<<blocks, threads, shmem, stream>>>(a);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const int nSlots = a.n_local_tiles * 64;
+    accumulateColors<<<(nSlots + 255) / 256, 256, 0, stream>>>(a);
+    return hipGetLastError();
+}
+
+hipError_t launchTwoPass(const RenderArgs& a, bool count, int blocks, int threads, hipStream_t stream) {
+    const size_t shmem = (size_t)a.lds_bytes;
+    if (a.sc.normal_mapping)
+        return count ? launchTwoPassT<true, true, true>(a, blocks, threads, shmem, stream)
+                     : launchTwoPassT<false, true, true>(a, blocks, threads, shmem, stream);
+    const bool plain = a.sc.n_tris == 0 && !a.sc.has_pbr;
+    if (!count && plain) return launchTwoPassT<false, false, false>(a, blocks, threads, shmem, stream);
+    return count ? launchTwoPassT<true, true, false>(a, blocks, threads, shmem, stream)
+                 : launchTwoPassT<false, true, false>(a, blocks, threads, shmem, stream);
 }
 
 hipError_t launchRender(const RenderArgs& a, bool lds, bool count, int blocks, int threads, hipStream_t stream) {
