@@ -66,6 +66,48 @@ struct Rng {
     }
     // randomFloat(min, max), R/src/Core/RTWeekend.h:33-36
     __device__ __forceinline__ float next(float mn, float mx) { return mn + (mx - mn) * next(); }
+    // randomFloat(-1, 1) = -1 + 2 * (f - 1) with f = the mantissa trick's float in [1, 2).  f - 1 is exact, its
+    // double is exact, and the sum is a multiple of 2^-22 below 1 in magnitude, hence exact as well: the single
+    // rounding of the fused 2 f - 3 returns the same bits, in one instruction instead of three.
+    __device__ __forceinline__ float signedFrom(uint32_t inner) const {
+        uint32_t m = hashu(key ^ inner);
+        m &= 0x007FFFFFu;
+        m |= 0x3F800000u;
+        return __builtin_fmaf(2.0f, __uint_as_float(m), -3.0f);
+    }
+    __device__ __forceinline__ uint32_t innerOf(uint32_t c) const { return hashu(fbits((float)c)); }
+    // n consecutive draws of randomFloat(-1, 1), first draw first; one look at the counter for all of them
+    __device__ __forceinline__ void nextSigned2(float& a, float& b) {
+        const uint32_t c = counter;
+        counter += 2;
+        uint32_t i1, i2;
+        if (c + 2 < (uint32_t)kCounterLut) {
+            i1 = g_counterLut[c + 1];
+            i2 = g_counterLut[c + 2];
+        } else {
+            i1 = innerOf(c + 1);
+            i2 = innerOf(c + 2);
+        }
+        a = signedFrom(i1);
+        b = signedFrom(i2);
+    }
+    __device__ __forceinline__ void nextSigned3(float& a, float& b, float& cc) {
+        const uint32_t c = counter;
+        counter += 3;
+        uint32_t i1, i2, i3;
+        if (c + 3 < (uint32_t)kCounterLut) {
+            i1 = g_counterLut[c + 1];
+            i2 = g_counterLut[c + 2];
+            i3 = g_counterLut[c + 3];
+        } else {
+            i1 = innerOf(c + 1);
+            i2 = innerOf(c + 2);
+            i3 = innerOf(c + 3);
+        }
+        a = signedFrom(i1);
+        b = signedFrom(i2);
+        cc = signedFrom(i3);
+    }
 };
 
 struct V3 {
@@ -88,13 +130,13 @@ __device__ __forceinline__ V3 reflect(V3 I, V3 N) { return I - N * dot(N, I) * 2
 // randomVecInUnitSphere, R/src/Core/RTWeekend.cpp:3-12 (z, y, x draw order of the g++ build)
 __device__ __forceinline__ V3 randomInUnitSphere(Rng& rng) {
     for (;;) {
-        float z = rng.next(-1.0f, 1.0f), y = rng.next(-1.0f, 1.0f), x = rng.next(-1.0f, 1.0f);
+        float x, y, z;
+        rng.nextSigned3(z, y, x);
         V3 p{x, y, z};
         if (dot(p, p) >= 1.0f) continue;
         return p;
     }
 }
-
 // Scene arrays as the traversal sees them: either straight from HBM/L2 or staged in LDS.
 struct SceneView {
     const float4* nodes;    // reference-order entries
@@ -528,17 +570,22 @@ __device__ __forceinline__ float reflectance(float cosine, float refIdx) {
 // Returns true if the path continues with `out` and `atten`; false ends it with `emit`.
 // FULL = false: no material of the scene is a PBRMaterial (texture code left out).  NMAP = false: the scene
 // has normal mapping switched off (the reference's behaviour), and the code for it is left out.
+// Lambertian, Metal and PBR each draw exactly one point in the unit sphere and nothing before it, so the
+// rejection loop runs once for all the lanes of a wave, whatever their material, and the caller runs it
+// (`ball`; see drawsBall).  (Cut off after 1 / 2 / 3 / 4 candidates per SHADE execution, the lanes still without
+// a point coming back with the next execution: 24.4 / 21.3 / 20.55 / 20.25 ms against 20.2 -- lanes that wait
+// for another SHADE execution are missing from the box steps.)
+template <bool FULL = true>
+__device__ __forceinline__ bool drawsBall(int kind) {
+    return kind == 0 || kind == 1 || (FULL && kind == 4);
+}
 template <bool COUNT, bool FULL = true, bool NMAP = true>
-__device__ __forceinline__ bool scatter(const DevScene& sc, const SceneView& sv, const Ray& in, const Surface& s,
-                                        Rng& rng, Ray& out, V3& atten, V3& emit, Stats* st) {
-    const float4 m0 = sv.materials[2 * s.mat], m1 = sv.materials[2 * s.mat + 1];
+__device__ __forceinline__ bool scatter(const DevScene& sc, const float4& m0, const float4& m1, const Ray& in,
+                                        const Surface& s, const V3& ball, Rng& rng, Ray& out, V3& atten, V3& emit,
+                                        Stats* st) {
     const int kind = (int)fbits(m1.x);
     emit = {0.0f, 0.0f, 0.0f};
     out.o = s.p;
-    // Lambertian, Metal and PBR each draw exactly one point in the unit sphere and nothing before
-    // it, so the rejection loop runs once for all the lanes of a wave, whatever their material.
-    V3 ball{0.0f, 0.0f, 0.0f};
-    if (kind == 0 || kind == 1 || (FULL && kind == 4)) ball = randomInUnitSphere(rng);
     // likewise glm::normalize(rayIn.direction) of Metal, Dielectric and PBR
     V3 unitIn{0.0f, 0.0f, 0.0f};
     if (kind == 1 || kind == 2 || (FULL && kind == 4)) unitIn = normalize(in.d);
@@ -618,8 +665,7 @@ __device__ __forceinline__ Ray cameraRay(const DevScene& sc, float s, float t, R
     const float* c = sc.cam;
     float px, py;
     for (;;) {
-        py = rng.next(-1.0f, 1.0f);
-        px = rng.next(-1.0f, 1.0f);
+        rng.nextSigned2(py, px);
         if ((px * px + py * py) + 0.0f * 0.0f >= 1) continue;
         break;
     }
@@ -656,7 +702,10 @@ __device__ __forceinline__ V3 rayColor(const DevScene& sc, const SceneView& sv, 
         Surface s = surfaceAt(sc, sv, r, h);
         Ray out;
         V3 atten, emit;
-        if (!scatter<COUNT>(sc, sv, r, s, rng, out, atten, emit, st)) return throughput * emit;
+        const float4 m0 = sv.materials[2 * s.mat], m1 = sv.materials[2 * s.mat + 1];
+        V3 ball{0.0f, 0.0f, 0.0f};
+        if (drawsBall((int)fbits(m1.x))) ball = randomInUnitSphere(rng);
+        if (!scatter<COUNT>(sc, m0, m1, r, s, ball, rng, out, atten, emit, st)) return throughput * emit;
         throughput = throughput * atten;
         r = out;
         depth--;
@@ -1256,12 +1305,15 @@ __global__ void __launch_bounds__(WF_MAX_THREADS, LDS ? WF_WAVES_LDS : WF_WAVES_
             lap(T_GUARD);
             if (shading & !vouched) retraceInReferenceOrder();
             if (shading & vouched) {
-                if (COUNT) st.v[C_HITS]++;
                 Surface sf = surfaceAt<FULL>(sc, sv, r, h);
                 lap(T_SURFACE);
+                const float4 m0 = sv.materials[2 * sf.mat], m1 = sv.materials[2 * sf.mat + 1];
+                V3 ball{0.0f, 0.0f, 0.0f};
+                if (drawsBall<FULL>((int)fbits(m1.x))) ball = randomInUnitSphere(rng);
+                if (COUNT) st.v[C_HITS]++;
                 Ray out{r.o, r.d};
                 V3 atten{1.0f, 1.0f, 1.0f}, emit;
-                const bool alive = scatter<COUNT, FULL, NMAP>(sc, sv, r, sf, rng, out, atten, emit, &st);
+                const bool alive = scatter<COUNT, FULL, NMAP>(sc, m0, m1, r, sf, ball, rng, out, atten, emit, &st);
                 lap(T_SCATTER);
                 // The path goes on with throughput x attenuation and the scattered ray, unless it was absorbed
                 // (terminal radiance `emit`) or has used up its depth (terminal radiance 0 = `emit` of a
@@ -1587,7 +1639,10 @@ __global__ void __launch_bounds__(WF_MAX_THREADS, WF_WAVES_LDS) primaryPass(Rend
                 const Surface sf = surfaceAt<FULL>(sc, sv, r, h);
                 Ray out{r.o, r.d};
                 V3 atten{1.0f, 1.0f, 1.0f}, emit;
-                const bool alive = scatter<COUNT, FULL, NMAP>(sc, sv, r, sf, rng, out, atten, emit, &st);
+                const float4 m0 = sv.materials[2 * sf.mat], m1 = sv.materials[2 * sf.mat + 1];
+                V3 ball{0.0f, 0.0f, 0.0f};
+                if (drawsBall<FULL>((int)fbits(m1.x))) ball = randomInUnitSphere(rng);
+                const bool alive = scatter<COUNT, FULL, NMAP>(sc, m0, m1, r, sf, ball, rng, out, atten, emit, &st);
                 int depth = a.max_depth;
                 if (alive) {
                     thr = thr * atten;
@@ -1715,7 +1770,10 @@ __global__ void scatterKernel(DevScene sc, int n, const int* mat, const float* r
     out.o = {0, 0, 0};
     out.d = {0, 0, 0};
     V3 att{0, 0, 0}, emit;
-    bool ok = scatter<false>(sc, globalView(sc), in, s, rng, out, att, emit, nullptr);
+    const float4 m0 = sc.materials[2 * s.mat], m1 = sc.materials[2 * s.mat + 1];
+    V3 ball{0.0f, 0.0f, 0.0f};
+    if (drawsBall((int)fbits(m1.x))) ball = randomInUnitSphere(rng);
+    bool ok = scatter<false>(sc, m0, m1, in, s, ball, rng, out, att, emit, nullptr);
     atten[3 * i] = att.x;
     atten[3 * i + 1] = att.y;
     atten[3 * i + 2] = att.z;
@@ -1809,17 +1867,17 @@ hipError_t launchWavefront(const RenderArgs& a, bool lds, bool count, int blocks
 }
 
 // Two-pass launch (tables in LDS): primaryPass, the persistent loop over its records, the per-pixel sums.
-template <bool COUNT, bool FULL, bool NMAP>
+template <bool COUNT, bool FULL, bool NMAP, bool TIME = false>
 static hipError_t launchTwoPassT(const RenderArgs& a, int blocks, int threads, size_t shmem, hipStream_t stream) {
     (void)hipGetLastError();  // an earlier, unrelated failure must not be reported as this launch's
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(primaryPass<COUNT, FULL, NMAP>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(renderWavefront<true, COUNT, false, FULL, NMAP, true>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(renderWavefront<true, COUNT, TIME, FULL, NMAP, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     primaryPass<COUNT, FULL, NMAP><<<blocks, threads, shmem, stream>>>(a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    renderWavefront<true, COUNT, false, FULL, NMAP, true><<<blocks, threads, shmem, stream>>>(a);
+    renderWavefront<true, COUNT, TIME, FULL, NMAP, true><<<blocks, threads, shmem, stream>>>(a);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     const int nSlots = a.n_local_tiles * 64;
@@ -1829,6 +1887,7 @@ static hipError_t launchTwoPassT(const RenderArgs& a, int blocks, int threads, s
 
 hipError_t launchTwoPass(const RenderArgs& a, bool count, int blocks, int threads, hipStream_t stream) {
     const size_t shmem = (size_t)a.lds_bytes;
+    if (count && a.timing) return launchTwoPassT<false, true, false, true>(a, blocks, threads, shmem, stream);
     if (a.sc.normal_mapping)
         return count ? launchTwoPassT<true, true, true>(a, blocks, threads, shmem, stream)
                      : launchTwoPassT<false, true, true>(a, blocks, threads, shmem, stream);
