@@ -2,10 +2,11 @@
 max depth 50, one frame of 64 samples per pixel per GPU per step.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...; started without
+    a launcher, bench.py starts that command itself as a child process and passes its output on)
 
 One step = clear the accumulation buffer, one render call of `spp` samples of every owned pixel,
-(N > 1: one all-gather of the rank payloads over RCCL), the device resolve into the row-major
+(N > 1: one gather of the rank payloads to rank 0 over RCCL), the device resolve into the row-major
 RGBA8 frame the reference hands to glTexImage2D, and the copy of that frame (8.3 MB) to pinned
 host memory on rank 0.  The scene lives in device memory before timing starts.
 
@@ -20,6 +21,8 @@ import argparse
 import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import tempfile
 import time
@@ -90,7 +93,21 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the multi-rank path on fewer GPUs than ranks (ranks share devices, "
                          "the gather goes through host memory); not a measurement")
+    ap.add_argument("--exchange", default="gather", choices=["gather", "allgather"],
+                    help="per-frame exchange of the rank payloads: gather to rank 0, which alone resolves the frame "
+                         "(default), or all-gather to every rank")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Started without a launcher: start one rank per GPU under torch.distributed.run as a CHILD process
+        # (nothing in this process has touched the GPU yet), pass its output on and leave with its code.
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        child = subprocess.run(cmd, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
+        raise SystemExit(child.returncode)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -125,8 +142,10 @@ def main():
 
     n4 = tiling.payload_float4s(W, H, world)
     payload = torch.zeros(n4, 4, dtype=torch.float32, device=dev)
-    gathered = torch.zeros(world * n4, 4, dtype=torch.float32, device=dev) if world > 1 else None  # rank payloads end to end
+    # rank payloads end to end; with the root-only exchange only rank 0 holds them
+    gathered = torch.zeros(world * n4, 4, dtype=torch.float32, device=dev) if world > 1 else None
     frame8 = torch.zeros(H, W, 4, dtype=torch.uint8, device=dev) if world > 1 else None
+    exchange = [args.exchange]
     host8 = torch.zeros(H, W, 4, dtype=torch.uint8).pin_memory()   # what the application would upload as a texture
     ctx.set_target(W, H, rank, world, external_ptr=payload.data_ptr())
     kernel_ms = []
@@ -139,14 +158,23 @@ def main():
         if world == 1:
             ctx.read_rgba8_into(spp_step, host8.data_ptr())   # resolve + copy to the host; blocks
             return
+        # The one exchange of the frame.  Only rank 0 resolves, so by default the payloads are gathered there
+        # (33.2 MB x (N - 1) / N into one GPU); the all-gather moves N times as much.
         if args.backend == "nccl":
-            dist.all_gather_into_tensor(gathered, payload)
+            if exchange[0] == "allgather":
+                dist.all_gather_into_tensor(gathered, payload)
+            else:
+                dist.gather(payload, list(gathered.view(world, n4, 4).unbind(0)) if rank == 0 else None, dst=0)
         else:
             host = torch.empty(gathered.shape, dtype=gathered.dtype)
-            dist.all_gather_into_tensor(host, payload.cpu())
-            gathered.copy_(host)
-        ctx.resolve_gathered_rgba8(gathered.data_ptr(), world, spp_step, frame8.data_ptr())
+            if exchange[0] == "allgather":
+                dist.all_gather_into_tensor(host, payload.cpu())
+            else:
+                dist.gather(payload.cpu(), list(host.view(world, n4, 4).unbind(0)) if rank == 0 else None, dst=0)
+            if rank == 0 or exchange[0] == "allgather":
+                gathered.copy_(host)
         if rank == 0:
+            ctx.resolve_gathered_rgba8(gathered.data_ptr(), world, spp_step, frame8.data_ptr())
             host8.copy_(frame8, non_blocking=True)
 
     def fence():
@@ -175,6 +203,12 @@ def main():
     elapsed = timed(spp_weak, args.steps, args.warmup)
     # Strong scaling: ONE args.spp-sample frame split over the ranks (for one rank the same workload).
     elapsed_strong = timed(args.spp, args.steps, 1) if world > 1 else elapsed
+    # the other exchange, for comparison (same steps, same work)
+    elapsed_other = None
+    if world > 1:
+        exchange[0] = "allgather" if args.exchange == "gather" else "gather"
+        elapsed_other = timed(spp_weak, args.steps, 1)
+        exchange[0] = args.exchange
 
     # Kernel duration by HIP events on the launch stream, in separate untimed steps (reading an
     # event blocks the host, which must not sit inside the timed region).
@@ -206,7 +240,7 @@ def main():
                         f"({spp_weak} spp frame), max depth 50, progressive accumulation; a step ends with the "
                         f"RGBA8 frame in host memory",
             "samples_per_step": samples_per_step,
-            "parallelism": f"tiles8x8 sharded over {world} rank(s)" + ((", all-gather (RCCL)" if args.backend == "nccl" else ", all-gather (gloo rehearsal through host memory)") if world > 1 else ""),
+            "parallelism": f"tiles8x8 sharded over {world} rank(s)" + ((f", {args.exchange} (RCCL)" if args.backend == "nccl" else f", {args.exchange} (gloo rehearsal through host memory)") if world > 1 else ""),
             "render_kernels_ms": round(avg_kernel_ms, 4),
             "resolve_gather_copy_ms": round(ms_step - avg_kernel_ms, 4),
             "strong_scaling": {
@@ -216,6 +250,11 @@ def main():
             },
         },
     }
+
+    if elapsed_other is not None:
+        other = "allgather" if args.exchange == "gather" else "gather"
+        out["config"]["exchange"] = args.exchange
+        out["config"][f"resolve_gather_copy_ms_with_{other}"] = round(1e3 * elapsed_other / args.steps - avg_kernel_ms, 4)
 
     if args.check and world > 1:
         fence()
@@ -253,7 +292,7 @@ def main():
             "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_FP32_TFLOPS, 4),
             "traffic": prof.get("hbm_bytes_per_launch"),   # null when the PMC passes predate the kernel sources
-            "kernel": "rt::renderWavefront<true, false, false, false, false> (tables in LDS, spheres-only build)",
+            "kernel": "rt::renderWavefront<true, false, false, false, false, false> (tables in LDS, spheres-only build)",
             "kernel_ms": round(avg_kernel_ms, 4),
             "flops_per_sample": round(flops_per_sample, 1),
             "rays_per_sample": round(counters["rays"] / counters["samples"], 3),
@@ -268,13 +307,28 @@ def main():
             simd_cycles = prop.multi_processor_count * 4 * avg_kernel_ms * 1e-3 * SHADER_CLOCK_HZ
             out["roofline"]["valu_issue_frac"] = round(2.0 * valu / simd_cycles, 3)
             out["roofline"]["lane_utilisation"] = round(prof.get("lane_utilisation") or 0.0, 3)
+        # traffic, valu_issue_frac and lane_utilisation are not measured in this run: they come from the committed
+        # rocprofv3 PMC passes over this same workload, and only while the kernel sources are the ones profiled
+        out["roofline"]["pmc_source"] = "profiles/hbm_traffic.json" if prof else None
     ctx.close()
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # The CPU oracle (scalar restatement of the reference's algorithm) on this box's host cores,
         # on a bounded sample of the same workload; it is the checker elsewhere, here only timed.
         orc = load_oracle()
-        threads = max(1, min(16, int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))))
+        # Every core this process may run on (the affinity mask, further limited by a cgroup CPU quota when
+        # there is one): os.cpu_count() names the whole machine, of which a GPU box hands one job a share.
+        host_cpus = os.cpu_count() or 1
+        usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else host_cpus
+        quota = None
+        try:
+            with open("/sys/fs/cgroup/cpu.max") as f:
+                q, period = f.read().split()[:2]
+                if q != "max":
+                    quota = max(1, int(int(q) / int(period)))
+        except (OSError, ValueError):
+            pass
+        threads = max(1, min(usable, quota) if quota else usable)
         cpu_spp = 16
         o = orc.OracleScene()
         scenes.cover_scene(o, W, H, wrap_bvh=True)
@@ -304,7 +358,7 @@ def main():
         ppm = os.path.join(tempfile.gettempdir(), "image.ppm")
         rt.write_ppm(ppm, c1_rgba8)
         ppm_bytes = os.path.getsize(ppm)
-        t2 = max(1, threads - 2)
+        t2 = max(1, threads - 2)   # hardware_concurrency() - 2, R/src/Core/Raytracer.cpp:136
         t0 = time.perf_counter()
         c1.render(cw, ch, 0, cspp, MAX_DEPTH, rng_mode=1, order=1, threads=t2)
         dt_c1_t2 = time.perf_counter() - t0
@@ -312,6 +366,8 @@ def main():
             "value": round(W * H * cpu_spp / dt / 1e6, 3),
             "unit": "Msamples/s",
             "cores": threads,
+            "host_cpus": host_cpus,
+            "usable_cpus": {"affinity": usable, "cgroup_quota": quota},
             "kind": "port",
             "sample": f"same scene and camera, {W}x{H} at {cpu_spp} spp ({W * H * cpu_spp / 1e6:.1f} M samples), "
                       f"scalar CPU oracle with BVH, {threads} threads, {dt:.1f} s wall",

@@ -21,17 +21,35 @@ def free_port():
     return port
 
 
-def test_two_rank_bench_step_gathers_the_single_rank_frame():
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
-           "--spp", "2", "--backend", "gloo", "--check", "--no-cpu-baseline"]
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+@pytest.mark.parametrize("launcher,exchange", [("torchrun", "gather"), ("self", "allgather")])
+def test_two_rank_bench_step_gathers_the_single_rank_frame(launcher, exchange):
+    """launcher "self": `python bench.py --gpus 2` with no launcher around it -- bench.py starts
+    torch.distributed.run itself, as a child, and passes its output and exit code on."""
+    tail = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--spp", "2", "--backend", "gloo",
+            "--exchange", exchange, "--check", "--no-cpu-baseline"]
+    if launcher == "torchrun":
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", str(free_port())] + tail
+    else:
+        cmd = [sys.executable] + tail
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["MASTER_ADDR"] = "127.0.0.1"
     res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["gathered_frame_equals_single_rank_render"] is True
     assert out["config"]["samples_per_step"] == 1920 * 1080 * 2 * 2
+    # both exchanges are timed: the one asked for in the step, the other beside it
+    other = "allgather" if exchange == "gather" else "gather"
+    assert out["config"]["exchange"] == exchange and f"resolve_gather_copy_ms_with_{other}" in out["config"]
+
+
+def test_bench_refuses_a_world_size_that_is_not_its_gpu_count():
+    env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], cwd=ROOT, env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode != 0 and "WORLD_SIZE" in (res.stdout + res.stderr)
 
 
 RCCL_ONE_RANK = r"""
