@@ -785,7 +785,11 @@ int rt_upload_scene(rt_context* ctx, rt_scene* s) {
     if ((rc = devUpload(ctx, triF, &d.tri_frame))) return rc;
     d.normal_mapping = sc.normal_mapping ? 1 : 0;
     d.has_pbr = 0;
-    for (const auto& m : sc.materials) d.has_pbr |= m.kind == 4 ? 1 : 0;
+    d.has_dielectric = 0;
+    for (const auto& m : sc.materials) {
+        d.has_pbr |= m.kind == 4 ? 1 : 0;
+        d.has_dielectric |= m.kind == 2 ? 1 : 0;
+    }
     if ((rc = devUpload(ctx, triMat, &d.tri_mat))) return rc;
     if ((rc = devUpload(ctx, mats, &d.materials))) return rc;
     if ((rc = devUpload(ctx, texels, &d.texels))) return rc;

@@ -32,6 +32,7 @@ struct DevScene {
     int n_nodes, n_prim_refs, n_fast_nodes, n_fast_refs, n_spheres, n_tris, n_mats;
     int fast_oct_stride;      // > 0: fast_nodes holds 8 direction-ordered copies of this many entries each
     int has_pbr;              // 1: some material is a PBRMaterial
+    int has_dielectric;       // 1: some material is a Dielectric
     int normal_mapping;       // 1: PBR materials with a normal map shade with the mapped normal (off: as the reference, the map is ignored)
     int force_ref;            // 1: always walk `nodes` in the reference's order (diagnostics)
     // per-ray widening of the search structure's boxes for rays that start far from small primitives

@@ -9,6 +9,8 @@
 // R/ = /root/reference/Raytracing-In-A-Weekend/.
 #include "rt_device.h"
 
+#include <cstdlib>
+#include <cstring>
 #include <type_traits>
 
 namespace rt {
@@ -20,6 +22,23 @@ constexpr uint32_t kRefTri = 1u << 30;
 constexpr uint32_t kRefId = kRefTri - 1;
 constexpr uint32_t kNoHit = 0xFFFFFFFFu;
 constexpr float kTMin = 0.001f;  // R/src/Core/Raytracer.cpp:10
+
+// What a scene can hold, as far as the code compiled for it goes (template parameter HAS of the render kernels
+// and their helpers): code for what a scene does not hold is left out, and with it the registers it would occupy
+// in every lane through every operation.
+enum : int {
+    S_SPHERES = 1,  // Sphere primitives
+    S_TRIS = 2,     // Triangle primitives
+    S_PBR = 4,      // PBRMaterial (textures)
+    S_DIEL = 8,     // Dielectric (its Schlick term runs in double)
+    S_ALL = 15,
+    S_PLAIN = S_SPHERES | S_DIEL,  // the cover scene's kind: spheres with Lambertian / Metal / Dielectric / DiffuseLight
+    S_MESH = S_TRIS | S_PBR        // the Cornell box + vase kind: triangles with Lambertian / Metal / DiffuseLight / PBR
+};
+template <int HAS>
+__device__ __forceinline__ bool isTriangleRef(uint32_t ref) {
+    return (HAS & S_TRIS) && (!(HAS & S_SPHERES) || (ref & (1u << 30)));
+}
 
 __device__ __forceinline__ uint32_t fbits(float f) { return __float_as_uint(f); }
 
@@ -44,8 +63,15 @@ constexpr int kCounterLut = 256;
 __shared__ uint32_t g_counterLut[kCounterLut];
 __shared__ int g_cancelSeen;  // set by the workgroup's first wave once it has read the caller's cancel flag as up
 
-__device__ __forceinline__ void fillCounterLut() {
+// stbi_loadf's 8-bit -> float map (DevScene::lut), staged by the kernels that sample textures: a texel fetch is
+// followed by three look-ups, which then cost an LDS read each instead of a trip to L1 / L2
+__shared__ float g_texLut[256];
+
+template <bool TEX = false>
+__device__ __forceinline__ void fillCounterLut(const float* texLut = nullptr) {
     for (int i = threadIdx.x; i < kCounterLut; i += blockDim.x) g_counterLut[i] = hashu(fbits((float)i));
+    if (TEX)
+        for (int i = threadIdx.x; i < 256; i += blockDim.x) g_texLut[i] = texLut[i];
     if (threadIdx.x == 0) g_cancelSeen = 0;
     __syncthreads();
 }
@@ -267,12 +293,11 @@ __device__ __forceinline__ float farRayPad(const DevScene& sc, const V3& o) {
 // Sphere::Hit / Triangle::Hit (R/src/Core/Hittable.h:228-255, 58-141) for one leaf reference:
 // true with the hit distance (and a triangle's barycentrics) if the primitive is hit within
 // [0.001, tMax].  `tMax < t` rejects, equality accepts, as in the reference.
-// FULL = false: the scene holds spheres only (the triangle branch is left out of the code).
-template <bool COUNT, bool FULL = true>
+template <bool COUNT, int HAS = S_ALL>
 __device__ __forceinline__ bool primRoot(const SceneView& sv, uint32_t ref, const Ray& r, float a, float tMax, float& tOut,
                                          float& uOut, float& vOut, Stats* st) {
     const uint32_t id = ref & kRefId;
-    if (FULL && (ref & kRefTri)) {
+    if (isTriangleRef<HAS>(ref)) {
         // edges are precomputed on the host with the reference's two subtractions
         if (COUNT) st->v[C_TRI]++;
         const float4 q0 = sv.tris[3 * id], q1 = sv.tris[3 * id + 1], q2 = sv.tris[3 * id + 2];
@@ -296,6 +321,7 @@ __device__ __forceinline__ bool primRoot(const SceneView& sv, uint32_t ref, cons
         vOut = v;
         return true;
     }
+    if (!(HAS & S_SPHERES)) return false;
     if (COUNT) st->v[C_SPHERE]++;
     const float4 s = sv.spheres[id];
     V3 oc{r.o.x - s.x, r.o.y - s.y, r.o.z - s.z};
@@ -326,9 +352,9 @@ __device__ __forceinline__ void primRef(const SceneView& sv, uint32_t ref, const
     }
 }
 
-template <bool FULL = true>
+template <int HAS = S_ALL>
 __device__ __forceinline__ int refOrder(const SceneView& sv, uint32_t ref) {
-    return (FULL && (ref & kRefTri)) ? sv.tri_ord[ref & kRefId] : sv.sphere_ord[ref & kRefId];
+    return isTriangleRef<HAS>(ref) ? sv.tri_ord[ref & kRefId] : sv.sphere_ord[ref & kRefId];
 }
 
 // Update rule for primitives that arrive in any order: smallest hit distance wins, and of two
@@ -419,10 +445,10 @@ __device__ __forceinline__ Hit traverseFast(const SceneView& sv, int n_nodes, co
 // The condition under which the reference's walk returns exactly the hit found by the search
 // structure: the innermost reference box above the winner, and every enclosing box that does
 // not contain it, pass the reference's slab test with tMax = the winner's distance.
-template <bool COUNT, bool FULL = true>
+template <bool COUNT, int HAS = S_ALL>
 __device__ __forceinline__ bool guardsPass(const SceneView& sv, const Ray& r, float invx, float invy, float invz, const Hit& h,
                                            Stats* st) {
-    int g = sv.prim_guard[refOrder<FULL>(sv, h.ref)];
+    int g = sv.prim_guard[refOrder<HAS>(sv, h.ref)];
     while (g >= 0) {
         if (COUNT) st->v[C_NODE]++;
         if (!slabPass(sv.nodes[2 * g], sv.nodes[2 * g + 1], r, invx, invy, invz, h.t)) return false;
@@ -469,7 +495,7 @@ struct Surface {
 
 // The HitRecord fields of the closest hit, computed once after traversal from (primitive, t):
 // same expressions as Sphere::Hit (Hittable.h:248-252) and Triangle::Hit (Hittable.h:86-107).
-template <bool FULL = true>
+template <int HAS = S_ALL>
 __device__ __forceinline__ Surface surfaceAt(const DevScene& sc, const SceneView& sv, const Ray& r, const Hit& h) {
     Surface s;
     s.p = r.o + h.t * r.d;
@@ -477,7 +503,7 @@ __device__ __forceinline__ Surface surfaceAt(const DevScene& sc, const SceneView
     s.v = 0.0f;
     s.front = false;
     const uint32_t id = h.ref & kRefId;
-    if (FULL && (h.ref & kRefTri)) {
+    if (isTriangleRef<HAS>(h.ref)) {
         const float4 q1 = sv.tris[3 * id + 1], q2 = sv.tris[3 * id + 2];
         const float4 a0 = sc.tri_shade[4 * id], a1 = sc.tri_shade[4 * id + 1], a2 = sc.tri_shade[4 * id + 2],
                      a3 = sc.tri_shade[4 * id + 3];
@@ -517,15 +543,23 @@ __device__ __forceinline__ Surface surfaceAt(const DevScene& sc, const SceneView
 // Texture::At, R/src/Material/Texture.h:37-43: nearest texel, row stride = height, and the
 // 8-bit -> float map of stbi_loadf.  Out-of-range indices are clamped (the reference reads
 // out of bounds there).
-__device__ __forceinline__ V3 textureAt(const DevScene& sc, int tex, float u, float v) {
+__device__ __forceinline__ uint32_t texelAt(const DevScene& sc, int tex, float u, float v) {
     const int4 d = sc.tex_desc[tex];
     int tx = (int)((u * d.y) - 0.5f);
     int ty = (int)(((1 - v) * d.z) - 0.5f);
     long long idx = (long long)ty * d.z + tx;
     const long long n = (long long)d.y * d.z;
     idx = idx < 0 ? 0 : (idx >= n ? n - 1 : idx);
-    const uint32_t px = sc.texels[(size_t)d.x + (size_t)idx];
+    return sc.texels[(size_t)d.x + (size_t)idx];
+}
+// STAGED: the kernel has the map in LDS (fillCounterLut with the scene's table)
+template <bool STAGED = false>
+__device__ __forceinline__ V3 texelColour(const DevScene& sc, uint32_t px) {
+    if (STAGED) return {g_texLut[px & 255u], g_texLut[(px >> 8) & 255u], g_texLut[(px >> 16) & 255u]};
     return {sc.lut[px & 255u], sc.lut[(px >> 8) & 255u], sc.lut[(px >> 16) & 255u]};
+}
+__device__ __forceinline__ V3 textureAt(const DevScene& sc, int tex, float u, float v) {
+    return texelColour(sc, texelAt(sc, tex, u, v));
 }
 
 // The same texel as plain byte / 255: a normal map holds directions, not colours, and must not go
@@ -568,18 +602,19 @@ __device__ __forceinline__ float reflectance(float cosine, float refIdx) {
 
 // Material::scatter for the five material kinds (R/src/Material/Material.h:22-160).
 // Returns true if the path continues with `out` and `atten`; false ends it with `emit`.
-// FULL = false: no material of the scene is a PBRMaterial (texture code left out).  NMAP = false: the scene
+// HAS without S_PBR: no material of the scene is a PBRMaterial (texture code left out); without S_DIEL: none is a
+// Dielectric.  NMAP = false: the scene
 // has normal mapping switched off (the reference's behaviour), and the code for it is left out.
 // Lambertian, Metal and PBR each draw exactly one point in the unit sphere and nothing before it, so the
 // rejection loop runs once for all the lanes of a wave, whatever their material, and the caller runs it
 // (`ball`; see drawsBall).  (Cut off after 1 / 2 / 3 / 4 candidates per SHADE execution, the lanes still without
 // a point coming back with the next execution: 24.4 / 21.3 / 20.55 / 20.25 ms against 20.2 -- lanes that wait
 // for another SHADE execution are missing from the box steps.)
-template <bool FULL = true>
+template <int HAS = S_ALL>
 __device__ __forceinline__ bool drawsBall(int kind) {
-    return kind == 0 || kind == 1 || (FULL && kind == 4);
+    return kind == 0 || kind == 1 || ((HAS & S_PBR) && kind == 4);
 }
-template <bool COUNT, bool FULL = true, bool NMAP = true>
+template <bool COUNT, int HAS = S_ALL, bool NMAP = true, bool STAGED = false>
 __device__ __forceinline__ bool scatter(const DevScene& sc, const float4& m0, const float4& m1, const Ray& in,
                                         const Surface& s, const V3& ball, Rng& rng, Ray& out, V3& atten, V3& emit,
                                         Stats* st) {
@@ -588,7 +623,7 @@ __device__ __forceinline__ bool scatter(const DevScene& sc, const float4& m0, co
     out.o = s.p;
     // likewise glm::normalize(rayIn.direction) of Metal, Dielectric and PBR
     V3 unitIn{0.0f, 0.0f, 0.0f};
-    if (kind == 1 || kind == 2 || (FULL && kind == 4)) unitIn = normalize(in.d);
+    if (kind == 1 || ((HAS & S_DIEL) && kind == 2) || ((HAS & S_PBR) && kind == 4)) unitIn = normalize(in.d);
     if (kind == 0) {  // Lambertian, Material.h:22-36
         if (COUNT) st->v[C_LAMB]++;
         V3 dir = s.n + normalize(ball);
@@ -604,7 +639,7 @@ __device__ __forceinline__ bool scatter(const DevScene& sc, const float4& m0, co
         atten = {m0.x, m0.y, m0.z};
         return dot(out.d, s.n) > 0;
     }
-    if (kind == 2) {  // Dielectric, Material.h:65-95
+    if ((HAS & S_DIEL) && kind == 2) {  // Dielectric, Material.h:65-95
         if (COUNT) st->v[C_DIEL]++;
         atten = {1.0f, 1.0f, 1.0f};
         const float ir = m0.w;
@@ -624,7 +659,7 @@ __device__ __forceinline__ bool scatter(const DevScene& sc, const float4& m0, co
         }
         return true;
     }
-    if (kind == 3 || !FULL) {  // DiffuseLight, Material.h:103-110
+    if (kind == 3 || !(HAS & S_PBR)) {  // DiffuseLight, Material.h:103-110
         if (COUNT) st->v[C_LIGHT]++;
         emit = {m0.x, m0.y, m0.z};
         return false;
@@ -646,10 +681,13 @@ __device__ __forceinline__ bool scatter(const DevScene& sc, const float4& m0, co
                                (T.z * m.x + B.z * m.y) + N.z * m.z});
         }
     }
-    atten = textureAt(sc, texD, s.u, s.v);
+    // both texels are asked for before either is used: two trips to memory side by side instead of one after the other
+    const uint32_t texelD = texelAt(sc, texD, s.u, s.v);
+    const uint32_t texelR = texR >= 0 ? texelAt(sc, texR, s.u, s.v) : 0u;
+    atten = texelColour<STAGED>(sc, texelD);
     if (texR >= 0) {
         V3 reflected = reflect(unitIn, nrm);
-        V3 rough = textureAt(sc, texR, s.u, s.v);
+        V3 rough = texelColour<STAGED>(sc, texelR);
         out.d = reflected + rough * ball;
         return dot(out.d, nrm) > 0;
     }
@@ -915,12 +953,12 @@ __device__ __forceinline__ int popc64(unsigned long long m) {
 // SPLIT: second pass of a two-pass launch.  primaryPass() has traced and shaded every path's camera ray a whole
 // tile at a time and left one record per path that goes on; NEWPATH then hands a lane the next record instead of
 // a pixel sample, and the queue counts chunks of 64 records.
-template <bool LDS, bool COUNT, bool TIME = false, bool FULL = true, bool NMAP = false, bool SPLIT = false>
+template <bool LDS, bool COUNT, bool TIME = false, int HAS = S_ALL, bool NMAP = false, bool SPLIT = false>
 __global__ void __launch_bounds__(WF_MAX_THREADS, LDS ? WF_WAVES_LDS : WF_WAVES_GLOBAL) renderWavefront(RenderArgs a) {
     const DevScene& sc = a.sc;
     // a first pass that was cut short has not written all its records: nothing to go on with
     if (SPLIT && a.queue[1]) return;
-    fillCounterLut();
+    fillCounterLut<(HAS & S_PBR) != 0>(sc.lut);
     SceneView sv;
     if (LDS) {
         sv = stageScene(sc, a.knob[2] != 0, true);
@@ -952,7 +990,8 @@ __global__ void __launch_bounds__(WF_MAX_THREADS, LDS ? WF_WAVES_LDS : WF_WAVES_
     Rng rng{0u, 0u};
     Ray r{{0.f, 0.f, 0.f}, {0.f, 0.f, 1.f}};
     float invx = 0.f, invy = 0.f, invz = 0.f;
-    float aa = 1.f;  // dot(d, d); the spheres-only build forms it where it is needed instead
+    float aa = 1.f;  // dot(d, d) for Sphere::Hit; a build for spheres alone forms it where it is needed instead
+    constexpr bool carriesAa = (HAS & S_TRIS) && (HAS & S_SPHERES);
     float nox = 0.f, noy = 0.f, noz = 0.f;  // -origin / direction, for the search structure's box test
     float epad = 0.f;                       // this ray's widening of every box (farRayPad); zero nearly always
     Hit h{0.f, kNoHit, 0.f, 0.f};
@@ -1039,7 +1078,7 @@ __global__ void __launch_bounds__(WF_MAX_THREADS, LDS ? WF_WAVES_LDS : WF_WAVES_
         invx = 1.0f / r.d.x;
         invy = 1.0f / r.d.y;
         invz = 1.0f / r.d.z;
-        if (FULL) aa = dot(r.d, r.d);
+        if (carriesAa) aa = dot(r.d, r.d);
         h.t = __builtin_inff();
         h.ref = kNoHit;
         // with direction-ordered copies of the search structure: the copy for this ray's signs
@@ -1220,17 +1259,17 @@ __global__ void __launch_bounds__(WF_MAX_THREADS, LDS ? WF_WAVES_LDS : WF_WAVES_
                             // the reference-order walk tests against the running closest distance and takes
                             // every hit; the search-structure walk tests without a limit and orders the hits.
                             float t, u = mode ? h.bu : 0.0f, v = mode ? h.bv : 0.0f;
-                            if (primRoot<COUNT, FULL>(sv, ref, r, FULL ? aa : dot(r.d, r.d), mode ? h.t : __builtin_inff(), t, u, v, &st)) {
+                            if (primRoot<COUNT, HAS>(sv, ref, r, carriesAa ? aa : dot(r.d, r.d), mode ? h.t : __builtin_inff(), t, u, v, &st)) {
                                 bool take = true;
                                 if (!mode) {
                                     bad = t != t;
                                     take = !bad && (h.ref == kNoHit || t < h.t ||
-                                                    (t == h.t && refOrder<FULL>(sv, ref) > refOrder<FULL>(sv, h.ref)));
+                                                    (t == h.t && refOrder<HAS>(sv, ref) > refOrder<HAS>(sv, h.ref)));
                                 }
                                 if (take) {
                                     h.t = t;
                                     h.ref = ref & ~kRefLast;
-                                    if (FULL) {
+                                    if (HAS & S_TRIS) {
                                         h.bu = u;
                                         h.bv = v;
                                     }
@@ -1301,19 +1340,19 @@ __global__ void __launch_bounds__(WF_MAX_THREADS, LDS ? WF_WAVES_LDS : WF_WAVES_
             // the compiler copy the whole lane state.
             const bool shading = op == OP_SHADE;
             bool vouched = false;
-            if (shading) vouched = mode != 0 || guardsPass<COUNT, FULL>(sv, r, invx, invy, invz, h, &st);
+            if (shading) vouched = mode != 0 || guardsPass<COUNT, HAS>(sv, r, invx, invy, invz, h, &st);
             lap(T_GUARD);
             if (shading & !vouched) retraceInReferenceOrder();
             if (shading & vouched) {
-                Surface sf = surfaceAt<FULL>(sc, sv, r, h);
+                Surface sf = surfaceAt<HAS>(sc, sv, r, h);
                 lap(T_SURFACE);
                 const float4 m0 = sv.materials[2 * sf.mat], m1 = sv.materials[2 * sf.mat + 1];
                 V3 ball{0.0f, 0.0f, 0.0f};
-                if (drawsBall<FULL>((int)fbits(m1.x))) ball = randomInUnitSphere(rng);
+                if (drawsBall<HAS>((int)fbits(m1.x))) ball = randomInUnitSphere(rng);
                 if (COUNT) st.v[C_HITS]++;
                 Ray out{r.o, r.d};
                 V3 atten{1.0f, 1.0f, 1.0f}, emit;
-                const bool alive = scatter<COUNT, FULL, NMAP>(sc, m0, m1, r, sf, ball, rng, out, atten, emit, &st);
+                const bool alive = scatter<COUNT, HAS, NMAP, true>(sc, m0, m1, r, sf, ball, rng, out, atten, emit, &st);
                 lap(T_SCATTER);
                 // The path goes on with throughput x attenuation and the scattered ray, unless it was absorbed
                 // (terminal radiance `emit`) or has used up its depth (terminal radiance 0 = `emit` of a
@@ -1496,7 +1535,7 @@ __global__ void __launch_bounds__(WF_MAX_THREADS, LDS ? WF_WAVES_LDS : WF_WAVES_
 // record_counts[chunk]: no atomic is involved, and the loop may take them in any order, since a path's radiance
 // is a function of (pixel, sample) alone.
 // Requires the tables in LDS (walk entries) and max_depth >= 1.
-template <bool COUNT, bool FULL, bool NMAP>
+template <bool COUNT, int HAS, bool NMAP>
 __global__ void __launch_bounds__(WF_MAX_THREADS, WF_WAVES_LDS) primaryPass(RenderArgs a) {
     const DevScene& sc = a.sc;
     fillCounterLut();
@@ -1602,14 +1641,14 @@ __global__ void __launch_bounds__(WF_MAX_THREADS, WF_WAVES_LDS) primaryPass(Rend
                     p += 1;
                     if (pass) {
                         float t, u = 0.0f, v = 0.0f;
-                        if (primRoot<COUNT, FULL>(sv, ref, r, aa, __builtin_inff(), t, u, v, &st)) {
+                        if (primRoot<COUNT, HAS>(sv, ref, r, aa, __builtin_inff(), t, u, v, &st)) {
                             if (t != t) {
                                 bad = true;
                             } else if (h.ref == kNoHit || t < h.t ||
-                                       (t == h.t && refOrder<FULL>(sv, ref) > refOrder<FULL>(sv, h.ref))) {
+                                       (t == h.t && refOrder<HAS>(sv, ref) > refOrder<HAS>(sv, h.ref))) {
                                 h.t = t;
                                 h.ref = ref & ~kRefLast;
-                                if (FULL) {
+                                if (HAS & S_TRIS) {
                                     h.bu = u;
                                     h.bv = v;
                                 }
@@ -1626,7 +1665,7 @@ __global__ void __launch_bounds__(WF_MAX_THREADS, WF_WAVES_LDS) primaryPass(Rend
         if (in) {
             const bool hit = h.ref != kNoHit;
             bool vouched = usable & !bad;
-            if (vouched & hit) vouched = guardsPass<COUNT, FULL>(sv, r, invx, invy, invz, h, &st);
+            if (vouched & hit) vouched = guardsPass<COUNT, HAS>(sv, r, invx, invy, invz, h, &st);
             if (!vouched) {
                 if (COUNT && usable) st.v[C_FALLBACK]++;
                 fate = 2;
@@ -1636,13 +1675,13 @@ __global__ void __launch_bounds__(WF_MAX_THREADS, WF_WAVES_LDS) primaryPass(Rend
                 a.colors[unit] = Radiance{cc.x, cc.y, cc.z};
             } else {
                 if (COUNT) st.v[C_HITS]++;
-                const Surface sf = surfaceAt<FULL>(sc, sv, r, h);
+                const Surface sf = surfaceAt<HAS>(sc, sv, r, h);
                 Ray out{r.o, r.d};
                 V3 atten{1.0f, 1.0f, 1.0f}, emit;
                 const float4 m0 = sv.materials[2 * sf.mat], m1 = sv.materials[2 * sf.mat + 1];
                 V3 ball{0.0f, 0.0f, 0.0f};
-                if (drawsBall<FULL>((int)fbits(m1.x))) ball = randomInUnitSphere(rng);
-                const bool alive = scatter<COUNT, FULL, NMAP>(sc, m0, m1, r, sf, ball, rng, out, atten, emit, &st);
+                if (drawsBall<HAS>((int)fbits(m1.x))) ball = randomInUnitSphere(rng);
+                const bool alive = scatter<COUNT, HAS, NMAP>(sc, m0, m1, r, sf, ball, rng, out, atten, emit, &st);
                 int depth = a.max_depth;
                 if (alive) {
                     thr = thr * atten;
@@ -1826,18 +1865,30 @@ __global__ void __launch_bounds__(256) resolveKernel(const float4* payloads, siz
 }
 
 // ------------------------------------------------------------------ launch wrappers
-template <bool LDS, bool COUNT, bool TIME = false, bool FULL = true, bool NMAP = false>
+template <bool LDS, bool COUNT, bool TIME = false, int HAS = S_ALL, bool NMAP = false>
 static hipError_t launchWavefrontT(const RenderArgs& a, int blocks, int threads, size_t shmem, hipStream_t stream) {
     (void)hipGetLastError();  // an earlier, unrelated failure must not be reported as this launch's
     if (LDS)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(renderWavefront<LDS, COUNT, TIME, FULL, NMAP>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(renderWavefront<LDS, COUNT, TIME, HAS, NMAP>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    renderWavefront<LDS, COUNT, TIME, FULL, NMAP><<<blocks, threads, shmem, stream>>>(a);
+    renderWavefront<LDS, COUNT, TIME, HAS, NMAP><<<blocks, threads, shmem, stream>>>(a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const int nSlots = a.n_local_tiles * 64;
     accumulateColors<<<(nSlots + 255) / 256, 256, 0, stream>>>(a);
     return hipGetLastError();
+}
+
+// Which build of the loop a scene runs: the one that holds code for what the scene holds and nothing else.
+// Spheres without PBR materials (the cover scene) leave the triangle and texture code out; triangles without
+// Dielectric materials (the Cornell box with the vase, the mesh scenes) leave out the sphere code and the Schlick
+// term's double arithmetic.  Fewer registers are then live in every lane through every operation.
+static int sceneKind(const DevScene& sc) {
+    const char* force = std::getenv("RT_SCENE_KIND");  // "all": the general build whatever the scene holds (A/B runs)
+    if (force && std::strcmp(force, "all") == 0) return S_ALL;
+    if (sc.n_tris == 0 && !sc.has_pbr) return S_PLAIN;
+    if (sc.n_spheres == 0 && !sc.has_dielectric) return S_MESH;
+    return S_ALL;
 }
 
 hipError_t launchWavefront(const RenderArgs& a, bool lds, bool count, int blocks, int threads, hipStream_t stream) {
@@ -1848,36 +1899,40 @@ hipError_t launchWavefront(const RenderArgs& a, bool lds, bool count, int blocks
                    : launchWavefrontT<false, false, true>(a, blocks, threads, 0, stream);
     // scenes with normal mapping switched on run the build that has the code for it (counting launches of such
     // scenes too: the mapped normal changes the paths)
-    if (a.sc.normal_mapping && !a.timing) {
-        if (lds) return count ? launchWavefrontT<true, true, false, true, true>(a, blocks, threads, shmem, stream)
-                              : launchWavefrontT<true, false, false, true, true>(a, blocks, threads, shmem, stream);
-        return count ? launchWavefrontT<false, true, false, true, true>(a, blocks, threads, 0, stream)
-                     : launchWavefrontT<false, false, false, true, true>(a, blocks, threads, 0, stream);
+    if (a.sc.normal_mapping) {
+        if (lds) return count ? launchWavefrontT<true, true, false, S_ALL, true>(a, blocks, threads, shmem, stream)
+                              : launchWavefrontT<true, false, false, S_ALL, true>(a, blocks, threads, shmem, stream);
+        return count ? launchWavefrontT<false, true, false, S_ALL, true>(a, blocks, threads, 0, stream)
+                     : launchWavefrontT<false, false, false, S_ALL, true>(a, blocks, threads, 0, stream);
     }
-    // scenes of spheres without PBR materials run a build of the loop that leaves the triangle and texture
-    // code out (fewer registers held by every lane through every operation)
-    const bool plain = a.sc.n_tris == 0 && !a.sc.has_pbr;
-    if (!count && plain)
-        return lds ? launchWavefrontT<true, false, false, false>(a, blocks, threads, shmem, stream)
-                   : launchWavefrontT<false, false, false, false>(a, blocks, threads, 0, stream);
-    if (lds) return count ? launchWavefrontT<true, true>(a, blocks, threads, shmem, stream)
-                          : launchWavefrontT<true, false>(a, blocks, threads, shmem, stream);
-    return count ? launchWavefrontT<false, true>(a, blocks, threads, 0, stream)
-                 : launchWavefrontT<false, false>(a, blocks, threads, 0, stream);
+    if (count)
+        return lds ? launchWavefrontT<true, true>(a, blocks, threads, shmem, stream)
+                   : launchWavefrontT<false, true>(a, blocks, threads, 0, stream);
+    switch (sceneKind(a.sc)) {
+        case S_PLAIN:
+            return lds ? launchWavefrontT<true, false, false, S_PLAIN>(a, blocks, threads, shmem, stream)
+                       : launchWavefrontT<false, false, false, S_PLAIN>(a, blocks, threads, 0, stream);
+        case S_MESH:
+            return lds ? launchWavefrontT<true, false, false, S_MESH>(a, blocks, threads, shmem, stream)
+                       : launchWavefrontT<false, false, false, S_MESH>(a, blocks, threads, 0, stream);
+        default:
+            return lds ? launchWavefrontT<true, false>(a, blocks, threads, shmem, stream)
+                       : launchWavefrontT<false, false>(a, blocks, threads, 0, stream);
+    }
 }
 
 // Two-pass launch (tables in LDS): primaryPass, the persistent loop over its records, the per-pixel sums.
-template <bool COUNT, bool FULL, bool NMAP, bool TIME = false>
+template <bool COUNT, int HAS, bool NMAP, bool TIME = false>
 static hipError_t launchTwoPassT(const RenderArgs& a, int blocks, int threads, size_t shmem, hipStream_t stream) {
     (void)hipGetLastError();  // an earlier, unrelated failure must not be reported as this launch's
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(primaryPass<COUNT, FULL, NMAP>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(primaryPass<COUNT, HAS, NMAP>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(renderWavefront<true, COUNT, TIME, FULL, NMAP, true>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(renderWavefront<true, COUNT, TIME, HAS, NMAP, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    primaryPass<COUNT, FULL, NMAP><<<blocks, threads, shmem, stream>>>(a);
+    primaryPass<COUNT, HAS, NMAP><<<blocks, threads, shmem, stream>>>(a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    renderWavefront<true, COUNT, TIME, FULL, NMAP, true><<<blocks, threads, shmem, stream>>>(a);
+    renderWavefront<true, COUNT, TIME, HAS, NMAP, true><<<blocks, threads, shmem, stream>>>(a);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     const int nSlots = a.n_local_tiles * 64;
@@ -1887,14 +1942,13 @@ static hipError_t launchTwoPassT(const RenderArgs& a, int blocks, int threads, s
 
 hipError_t launchTwoPass(const RenderArgs& a, bool count, int blocks, int threads, hipStream_t stream) {
     const size_t shmem = (size_t)a.lds_bytes;
-    if (count && a.timing) return launchTwoPassT<false, true, false, true>(a, blocks, threads, shmem, stream);
+    if (count && a.timing) return launchTwoPassT<false, S_ALL, false, true>(a, blocks, threads, shmem, stream);
     if (a.sc.normal_mapping)
-        return count ? launchTwoPassT<true, true, true>(a, blocks, threads, shmem, stream)
-                     : launchTwoPassT<false, true, true>(a, blocks, threads, shmem, stream);
-    const bool plain = a.sc.n_tris == 0 && !a.sc.has_pbr;
-    if (!count && plain) return launchTwoPassT<false, false, false>(a, blocks, threads, shmem, stream);
-    return count ? launchTwoPassT<true, true, false>(a, blocks, threads, shmem, stream)
-                 : launchTwoPassT<false, true, false>(a, blocks, threads, shmem, stream);
+        return count ? launchTwoPassT<true, S_ALL, true>(a, blocks, threads, shmem, stream)
+                     : launchTwoPassT<false, S_ALL, true>(a, blocks, threads, shmem, stream);
+    if (!count && sceneKind(a.sc) == S_PLAIN) return launchTwoPassT<false, S_PLAIN, false>(a, blocks, threads, shmem, stream);
+    return count ? launchTwoPassT<true, S_ALL, false>(a, blocks, threads, shmem, stream)
+                 : launchTwoPassT<false, S_ALL, false>(a, blocks, threads, shmem, stream);
 }
 
 hipError_t launchRender(const RenderArgs& a, bool lds, bool count, int blocks, int threads, hipStream_t stream) {
