@@ -60,6 +60,62 @@ def test_million_triangle_instanced_scene(rt, orc, scenes, gpu_ctx):
         gpu_ctx.set_reference_traversal(False)
 
 
+def test_ten_million_triangle_scene_at_its_size(rt, orc, scenes, gpu_ctx):
+    """The large-mesh configuration at its full size: 3,623 baked instances of the brass vase = 9,999,480
+    triangles (+ the Cornell box) under one unlimited-depth reference BVH, at 1920x1080.  The search structure
+    has more than 2 M entries, so it is held ONCE (no direction-ordered copies) and the loop walks it with the
+    general box test -- the only configuration that takes that path.  Three oracle row pairs bit-exact, the
+    reference-order walk and the device-built structure give the same image."""
+    mesh = scenes.load_gltf_mesh(VASE)
+    tex = {"diffuse": scenes.noise_texture(256, 1), "roughness": scenes.noise_texture(256, 2)}
+    w, h, copies = 1920, 1080, 3623
+    a = rt.Scene()
+    n = scenes.instanced_mesh_scene(a, mesh, copies, tex)
+    assert n == copies * 2760 == 9_999_480
+    info = a.flatten()
+    assert info.n_triangles == n + 12 and not info.fits_lds and info.n_nodes > 9_000_000
+    stride, entries = a.search_structure_octants()
+    assert stride == 0                                   # single copy: beyond the 2 M-entry limit of the copies
+    del entries
+    gpu_ctx.upload_scene(a)
+    gpu_ctx.set_target(w, h)
+    gpu_ctx.render(0, 1, 50)
+    gpu_ctx.sync()
+    got = gpu_ctx.read_accum()
+    assert np.isfinite(got).all() and got[..., :3].max() > 0
+    b = orc.OracleScene()
+    scenes.instanced_mesh_scene(b, mesh, copies, tex)
+    for row0 in (200, 540, 900):
+        want, _, _ = b.render(w, h, 0, 1, 50, rng_mode=1, order=1, threads=16, row0=row0, row1=row0 + 2)
+        assert np.array_equal(bits(got[row0:row0 + 2, :, :3]), bits(want[row0:row0 + 2, :, :3])), row0
+    del b
+    cnt = gpu_ctx.count(0, 1, 50)
+    assert cnt["samples"] == w * h and cnt["hits"] + cnt["misses"] == cnt["rays"]
+    assert cnt["fallbacks"] < 1e-3 * cnt["rays"] and cnt["tri_tests"] > 0 and cnt["sphere_tests"] == 0
+    # the reference-order walk over the ten-million-entry array returns the same image
+    gpu_ctx.set_reference_traversal(True)
+    try:
+        gpu_ctx.upload_scene(a)
+        gpu_ctx.set_target(w, h)
+        gpu_ctx.render(0, 1, 50)
+        gpu_ctx.sync()
+        assert np.array_equal(bits(gpu_ctx.read_accum()), bits(got))
+    finally:
+        gpu_ctx.set_reference_traversal(False)
+    # and so does the structure built on the device
+    dev = rt.Context(0)
+    try:
+        dev.set_device_build(True)
+        dev.upload_scene(a)
+        assert 0 < dev.last_build_ms() < 2000
+        dev.set_target(w, h)
+        dev.render(0, 1, 50)
+        dev.sync()
+        assert np.array_equal(bits(dev.read_accum()), bits(got))
+    finally:
+        dev.close()
+
+
 def test_4k_frame_one_of_eight_ranks(rt, orc, scenes, tiling, gpu_ctx):
     """3840x2160 split over a world of 8: the payload a rank renders holds exactly its tiles of the
     single-rank frame, bit for bit, and the frame itself matches the oracle on sampled rows."""
