@@ -142,6 +142,23 @@ int rt_scene_begin_mesh(rt_scene* s, const float* box6);
 int rt_scene_begin_list(rt_scene* s);
 int rt_scene_end_group(rt_scene* s);
 
+/* Instancing.  NO COUNTERPART IN THE REFERENCE, which has no instances: Mesh::processMesh bakes the model matrix
+ * into every vertex (R/src/Core/Mesh.cpp:106-208), so N placements of a mesh are N triangle lists and N trees.
+ * Opt-in, like normal mapping, and defined by the CPU oracle's Instance class: everything added between
+ * rt_scene_begin_prototype() and rt_scene_end_prototype() (which returns the prototype's number) forms an object
+ * in its own space that is NOT in the world; rt_scene_add_instance() puts a placement of it where an object
+ * would go (the world or an open group; rt_scene_wrap_bvh() builds the reference's BVHNode over placements
+ * like over any other object).  A placement's Hit(): its world-space box (the prototype's box corners under the
+ * model matrix), then the ray taken into object space -- direction NOT normalised, so hit distances are the same
+ * numbers in both spaces --, the prototype's own Hit(), and the normal brought back through
+ * mat3(transpose(inverse(model))) and normalised; the hit point is taken from the world ray.
+ * One level only (no instance inside a prototype).  Scenes with instances are rendered along the reference-order
+ * entries by the plain kernel (no search structure, no persistent loop), and not together with normal mapping.
+ * model16: column-major.  Returns the instance's number. */
+int rt_scene_begin_prototype(rt_scene* s);
+int rt_scene_end_prototype(rt_scene* s);
+int rt_scene_add_instance(rt_scene* s, int prototype, const float* model16);
+
 /* world = randomScene()  (R/src/RaytracingApplication.cpp:359-405), drawn in g++ argument order. */
 int rt_scene_random_scene(rt_scene* s);
 /* world = cornellBox()   (R/src/RaytracingApplication.cpp:407-478). */

@@ -274,6 +274,7 @@ struct HitRecord {  // R/src/Core/Hittable.h:10-28 (tangent/bitangent/modelMatri
     vec3 tangent, bitangent;  // per-triangle frame (normal mapping, an option the reference does not have working)
     bool hasFrame = false;
     int primKind = -1, primId = -1;  // bookkeeping for hit-index parity (0 sphere, 1 triangle)
+    int instance = -1;               // the placement the primitive was hit through (Instance), or -1
     void setFaceNormal(const Ray& r, vec3 outward) {
         frontFace = glmx::dot(r.direction, outward) < 0;
         normal = frontFace ? outward : -outward;
@@ -474,6 +475,7 @@ struct Triangle : Hittable {  // Hittable.h:46-220
         rec.mat = mat;
         rec.primKind = 1;
         rec.primId = id;
+        rec.instance = -1;
         return true;
     }
     bool BoundingBox(AABB& out) const override {  // :143-213, max starts at 1e-8 and flat axes get +-1
@@ -522,6 +524,7 @@ struct Sphere : Hittable {  // Hittable.h:222-270
         rec.mat = mat;
         rec.primKind = 0;
         rec.primId = id;
+        rec.instance = -1;
         return true;
     }
     bool BoundingBox(AABB& out) const override {
@@ -676,6 +679,71 @@ struct Mesh : Hittable {  // R/src/Core/Mesh.h:8-50
     int kindCode() const override { return 2; }
 };
 
+// A placement of a shared object.  NO COUNTERPART IN THE REFERENCE, which bakes every placement into world-space
+// triangles when a Mesh is built (R/src/Core/Mesh.cpp:106-208) and gives each its own tree; this class defines
+// the opt-in instanced mode of the product, the way PBR normal mapping is defined here.  Hit: the placement's
+// world-space box first (as Mesh::Hit tests its own), then the ray taken into object space -- origin as a
+// point, direction as a vector that is NOT normalised, so that hit distances are the same numbers in both
+// spaces -- the shared object's Hit with the caller's limits, and the record brought back: the point from the
+// world ray, the normal through mat3(transpose(inverse(M))) (what Mesh.cpp:144,148-150 applies to baked
+// normals) and normalised again.
+struct Instance : Hittable {
+    using mat4 = glmx::mat4;
+    std::shared_ptr<HittableList> object;
+    mat4 M, inv;
+    AABB box;
+    int id = 0;
+    void place(const mat4& model, int instanceId) {
+        using namespace glmx;
+        M = model;
+        inv = inverse(model);
+        id = instanceId;
+        AABB ob;
+        object->BoundingBox(ob);
+        float mn[3], mx[3];
+        for (int c = 0; c < 8; c++) {
+            vec3 p((c & 1) ? ob.maximum.x : ob.minimum.x, (c & 2) ? ob.maximum.y : ob.minimum.y,
+                   (c & 4) ? ob.maximum.z : ob.minimum.z);
+            float o[4];
+            mulPoint(M, p, 1.0f, o);
+            for (int k = 0; k < 3; k++) {
+                if (c == 0 || o[k] < mn[k]) mn[k] = o[k];
+                if (c == 0 || o[k] > mx[k]) mx[k] = o[k];
+            }
+        }
+        box = AABB{{mn[0], mn[1], mn[2]}, {mx[0], mx[1], mx[2]}};
+    }
+    Ray toObject(const Ray& r) const {
+        using namespace glmx;
+        float o[4];
+        mulPoint(inv, r.origin, 1.0f, o);
+        const vec3& d = r.direction;
+        vec3 dd((inv.c[0][0] * d.x + inv.c[1][0] * d.y) + inv.c[2][0] * d.z,
+                (inv.c[0][1] * d.x + inv.c[1][1] * d.y) + inv.c[2][1] * d.z,
+                (inv.c[0][2] * d.x + inv.c[1][2] * d.y) + inv.c[2][2] * d.z);
+        return Ray{vec3(o[0], o[1], o[2]), dd};
+    }
+    bool Hit(const Ray& r, float tMin, float tMax, HitRecord& rec, Rng& ctx) const override {
+        using namespace glmx;
+        if (ctx.cnt) ctx.cnt->nodeTests++;
+        if (!box.Hit(r, tMin, tMax)) return false;
+        const Ray ro = toObject(r);
+        if (!object->Hit(ro, tMin, tMax, rec, ctx)) return false;
+        rec.p = r.At(rec.t);
+        const vec3 n = rec.normal;
+        rec.normal = normalize(vec3((inv.c[0][0] * n.x + inv.c[0][1] * n.y) + inv.c[0][2] * n.z,
+                                    (inv.c[1][0] * n.x + inv.c[1][1] * n.y) + inv.c[1][2] * n.z,
+                                    (inv.c[2][0] * n.x + inv.c[2][1] * n.y) + inv.c[2][2] * n.z));
+        rec.instance = id;
+        return true;
+    }
+    bool BoundingBox(AABB& out) const override {
+        out = box;
+        return true;
+    }
+    int kindCode() const override { return 5; }
+};
+
 struct Camera {  // R/src/Core/Camera.h:3-40
     vec3 origin, lowerLeftCorner, horizontal, vertical, u, v, w;
     float lensRadius = 0;
@@ -713,6 +781,11 @@ struct Scene {
     int nSpheres = 0, nTriangles = 0;
     std::vector<std::shared_ptr<Sphere>> spheres;
     std::vector<std::shared_ptr<Triangle>> tris;
+    // objects that are placed by Instance rather than put into the world themselves; while one is being
+    // defined, everything that would go into the world goes into it
+    std::vector<std::shared_ptr<HittableList>> prototypes;
+    int openPrototype = -1, nInstances = 0;
+    std::vector<HPtr>& sink() { return openPrototype >= 0 ? prototypes[openPrototype]->objects : world.objects; }
     Scene() {
         rng.mode = Rng::MT;
         rng.gen = &gen;
@@ -753,7 +826,7 @@ struct Scene {
 void randomScene(Scene& sc) {
     Rng& rng = sc.rng;
     auto ground = sc.addMaterial(Material::LAMBERTIAN, vec3(0.5f, 0.5f, 0.5f), 0);
-    sc.world.objects.push_back(sc.makeSphere(vec3(0.0f, -1000.0f, 0.0f), 1000.0f, ground));
+    sc.sink().push_back(sc.makeSphere(vec3(0.0f, -1000.0f, 0.0f), 1000.0f, ground));
     for (int a = -11; a < 11; a++) {
         for (int b = -11; b < 11; b++) {
             float chooseMat = rng.randomFloat();
@@ -766,22 +839,22 @@ void randomScene(Scene& sc) {
                     vec3 second = rng.randomVec();  // right operand of operator* first
                     vec3 first = rng.randomVec();
                     vec3 albedo = first * second;
-                    sc.world.objects.push_back(sc.makeSphere(center, 0.2f, sc.addMaterial(Material::LAMBERTIAN, albedo, 0)));
+                    sc.sink().push_back(sc.makeSphere(center, 0.2f, sc.addMaterial(Material::LAMBERTIAN, albedo, 0)));
                 } else if (chooseMat < 0.95f) {
                     vec3 albedo = rng.randomVec(0.5f, 1.0f);
                     float fuzz = rng.randomFloat(0.0f, 0.5f);
-                    sc.world.objects.push_back(
+                    sc.sink().push_back(
                         sc.makeSphere(center, 0.2f, sc.addMaterial(Material::METAL, albedo, fuzz < 1 ? fuzz : 1)));
                 } else {
-                    sc.world.objects.push_back(sc.makeSphere(center, 0.2f, sc.addMaterial(Material::DIELECTRIC, vec3(), 1.5f)));
+                    sc.sink().push_back(sc.makeSphere(center, 0.2f, sc.addMaterial(Material::DIELECTRIC, vec3(), 1.5f)));
                 }
             }
         }
     }
-    sc.world.objects.push_back(sc.makeSphere(vec3(0.0f, 1.0f, 0.0f), 1.0f, sc.addMaterial(Material::DIELECTRIC, vec3(), 1.5f)));
-    sc.world.objects.push_back(
+    sc.sink().push_back(sc.makeSphere(vec3(0.0f, 1.0f, 0.0f), 1.0f, sc.addMaterial(Material::DIELECTRIC, vec3(), 1.5f)));
+    sc.sink().push_back(
         sc.makeSphere(vec3(-4.0f, 1.0f, 0.0f), 1.0f, sc.addMaterial(Material::LAMBERTIAN, vec3(0.4f, 0.2f, 0.1f), 0)));
-    sc.world.objects.push_back(
+    sc.sink().push_back(
         sc.makeSphere(vec3(4.0f, 1.0f, 0.0f), 1.0f, sc.addMaterial(Material::METAL, vec3(0.7f, 0.6f, 0.5f), 0.0f)));
 }
 
@@ -796,7 +869,7 @@ void cornellBox(Scene& sc) {
         v0.position = a;
         v1.position = b;
         v2.position = c;
-        sc.world.objects.push_back(sc.makeTriangle(v0, v1, v2, m));
+        sc.sink().push_back(sc.makeTriangle(v0, v1, v2, m));
     };
     tri({555, 0, 0}, {555, 555, 0}, {555, 555, 555}, green);
     tri({555, 0, 0}, {555, 555, 555}, {555, 0, 555}, green);
@@ -857,7 +930,7 @@ void addMesh(Scene& sc, const float* model16, int nVerts, const float* pos, cons
     auto mesh = std::make_shared<Mesh>();
     mesh->boundingBox = AABB{{mn[0], mn[1], mn[2]}, {mx[0], mx[1], mx[2]}};
     mesh->triangles.push_back(std::make_shared<BVHNode>(triangles, 0, triangles.size(), maxDepth, sc.rng));
-    sc.world.objects.push_back(mesh);
+    sc.sink().push_back(mesh);
 }
 
 // R/src/Core/Raytracer.cpp:3-20
@@ -954,7 +1027,7 @@ int orc_add_texture(void* s, int w, int h, const uint8_t* rgb) {
 }
 int orc_add_sphere(void* s, float cx, float cy, float cz, float r, int mat) {
     Scene& sc = *(Scene*)s;
-    sc.world.objects.push_back(sc.makeSphere(vec3(cx, cy, cz), r, sc.materials[mat].get()));
+    sc.sink().push_back(sc.makeSphere(vec3(cx, cy, cz), r, sc.materials[mat].get()));
     return sc.nSpheres - 1;
 }
 // pos[9], nrm[9] (all-zero first normal = flat shading), uv[6] (uv[0] == -1 means "none")
@@ -966,13 +1039,37 @@ int orc_add_triangle(void* s, const float* pos, const float* nrm, const float* u
         v[k].normal = vec3(nrm[3 * k], nrm[3 * k + 1], nrm[3 * k + 2]);
         v[k].textureCoord = vec3(uv[2 * k], uv[2 * k + 1], 0.0f);
     }
-    sc.world.objects.push_back(sc.makeTriangle(v[0], v[1], v[2], sc.materials[mat].get()));
+    sc.sink().push_back(sc.makeTriangle(v[0], v[1], v[2], sc.materials[mat].get()));
     return sc.nTriangles - 1;
 }
 void orc_add_mesh(void* s, const float* model16, int nVerts, const float* pos, const float* nrm, const float* uv,
                   int nTris, const uint32_t* idx, int mat, int maxDepth) {
     Scene& sc = *(Scene*)s;
     addMesh(sc, model16, nVerts, pos, nrm, uv, nTris, idx, sc.materials[mat].get(), maxDepth);
+}
+int orc_begin_prototype(void* s) {
+    Scene& sc = *(Scene*)s;
+    if (sc.openPrototype >= 0) return -1;
+    sc.prototypes.push_back(std::make_shared<HittableList>());
+    sc.openPrototype = (int)sc.prototypes.size() - 1;
+    return sc.openPrototype;
+}
+int orc_end_prototype(void* s) {
+    Scene& sc = *(Scene*)s;
+    const int id = sc.openPrototype;
+    sc.openPrototype = -1;
+    return id;
+}
+int orc_add_instance(void* s, int prototype, const float* model16) {
+    Scene& sc = *(Scene*)s;
+    if (prototype < 0 || prototype >= (int)sc.prototypes.size() || prototype == sc.openPrototype) return -1;
+    auto inst = std::make_shared<Instance>();
+    inst->object = sc.prototypes[prototype];
+    glmx::mat4 M;
+    std::memcpy(M.c, model16, sizeof(float) * 16);
+    inst->place(M, sc.nInstances++);
+    sc.sink().push_back(inst);
+    return inst->id;
 }
 // world = { BVHNode(world) }  (Bvh.h:17: unlimited depth), consuming the scene's RNG stream
 void orc_wrap_bvh(void* s) {

@@ -9,7 +9,7 @@
 Each case: upload, one timed launch (HIP events), path counters, and a bit-exact spot check of a few
 image rows against the CPU oracle.  Prints one JSON line per case.
 
-Usage: python profiles/bench_configs.py [c1] [c3] [c4] [c5s[:triangles]] [c5[:triangles]]
+Usage: python profiles/bench_configs.py [c1] [c3] [c4] [c5s[:triangles]] [c5[:triangles]] [c5i[:triangles]]
 """
 import json
 import os
@@ -99,6 +99,17 @@ def c5s(n_tris, w=1920, h=1080, spp=16, check=True):
         lambda s: scenes.instanced_mesh_scene(s, mesh, copies, tex), w, h, spp, [h // 2] if check else [], oracle_spp=1)
 
 
+def c5i(n_tris, w=1920, h=1080, spp=16, check=True):
+    """The large-mesh scene with true instances (rt_scene_add_instance): ONE vase held in its own space, placed
+    n_tris / 2,760 times.  Rendered by the plain kernel along the reference-order entries."""
+    mesh = scenes.load_gltf_mesh(G)
+    per = mesh["indices"].shape[0]
+    copies = max(1, n_tris // per)
+    tex = {"diffuse": scenes.noise_texture(1024, 1), "roughness": scenes.noise_texture(1024, 2), "normal": None}
+    run(f"C5 placed: {copies} placements of one vase ({per} triangles held, {copies * per} shown), {w}x{h}x{spp}",
+        lambda s: scenes.placed_mesh_scene(s, mesh, copies, tex), w, h, spp, [h // 2] if check else [], oracle_spp=1)
+
+
 def build_compare(n_tris, w=1920, h=1080, spp=16):
     """Host (surface-area heuristic, threaded) against device (linear BVH) build of the search structure
     for the instanced-vase scene: seconds until the scene is resident, and the render time each gives."""
@@ -161,6 +172,9 @@ if __name__ == "__main__":
             c4()
         elif a.startswith("build"):
             build_compare(int(float(a.split(":")[1])) if ":" in a else 1_000_000)
+        elif a.startswith("c5i"):
+            parts = a.split(":")
+            c5i(int(float(parts[1])) if len(parts) > 1 else 10_000_000, check=not (len(parts) > 2 and parts[2] == "nocheck"))
         elif a.startswith("c5s"):
             parts = a.split(":")   # c5s[:triangles[:nocheck]] -- nocheck skips the oracle rows (profiling runs)
             c5s(int(float(parts[1])) if len(parts) > 1 else 1_000_000, check=not (len(parts) > 2 and parts[2] == "nocheck"))

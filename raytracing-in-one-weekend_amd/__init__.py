@@ -69,6 +69,9 @@ SYMBOLS = {
     "rt_scene_begin_mesh": (_I, [_VP, _VP]),
     "rt_scene_begin_list": (_I, [_VP]),
     "rt_scene_end_group": (_I, [_VP]),
+    "rt_scene_begin_prototype": (_I, [_VP]),
+    "rt_scene_end_prototype": (_I, [_VP]),
+    "rt_scene_add_instance": (_I, [_VP, _I, _VP]),
     "rt_scene_random_scene": (_I, [_VP]),
     "rt_scene_cornell_box": (_I, [_VP]),
     "rt_scene_wrap_bvh": (_I, [_VP]),
@@ -244,6 +247,17 @@ class Scene:
 
     def end_group(self):
         _check(lib.rt_scene_end_group(self.h))
+
+    def begin_prototype(self):
+        """Objects added until end_prototype() form an object in its own space, placed by add_instance()."""
+        return _check(lib.rt_scene_begin_prototype(self.h))
+
+    def end_prototype(self):
+        return _check(lib.rt_scene_end_prototype(self.h))
+
+    def add_instance(self, prototype, model):
+        m = _f32(model, 16)
+        return _check(lib.rt_scene_add_instance(self.h, prototype, _p(m)))
 
     def random_scene(self):
         _check(lib.rt_scene_random_scene(self.h))

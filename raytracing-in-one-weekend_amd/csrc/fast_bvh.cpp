@@ -346,6 +346,14 @@ void Scene::buildFastStructure() {
     // box-tested entry the nearest enclosing one that does not contain its box
     f.prim_guard.assign(nRefs, -1);
     f.node_outer.assign(nNodes, -1);
+    if (!instances.empty()) {
+        // scenes with instances have no search structure: their rays walk the reference-order entries, which
+        // is where the placements and the prototypes' own entries are
+        f.fast_min_pad = 0.0f;
+        f.far_spheres = f.far_tris = 0;
+        f.world_refs.clear();
+        return;
+    }
     std::vector<int> open;  // stack of box-tested entries whose subtree contains the current entry
     auto box = [&](int e, float* mn, float* mx) {
         for (int k = 0; k < 3; k++) {

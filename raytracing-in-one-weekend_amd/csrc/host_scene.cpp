@@ -366,11 +366,55 @@ int Scene::addBox(const float* p0, const float* p1, int mat, const float* model1
 }
 
 void Scene::place(const Obj& o) {
-    if (open_groups_.empty())
-        world.push_back(o);
-    else
+    if (!open_groups_.empty())
         composites[open_groups_.back()].objs.push_back(o);
+    else if (open_prototype_ >= 0)
+        prototypes[open_prototype_].objs.push_back(o);
+    else
+        world.push_back(o);
     flat.valid = false;
+}
+
+int Scene::beginPrototype() {
+    if (open_prototype_ >= 0 || !open_groups_.empty()) return -1;
+    prototypes.emplace_back();
+    open_prototype_ = (int)prototypes.size() - 1;
+    return open_prototype_;
+}
+
+int Scene::endPrototype() {
+    if (open_prototype_ < 0 || !open_groups_.empty()) return -1;
+    const int id = open_prototype_;
+    open_prototype_ = -1;
+    return id;
+}
+
+int Scene::addInstance(int prototype, const float* model16) {
+    if (prototype < 0 || prototype >= (int)prototypes.size() || prototype == open_prototype_) return -1;
+    const Prototype& p = prototypes[prototype];
+    if (p.objs.empty()) return -1;
+    for (const Obj& o : p.objs)
+        if (o.kind == Obj::INSTANCE) return -1;  // one level of instancing
+    Instance in;
+    in.prototype = prototype;
+    std::memcpy(in.model, model16, sizeof in.model);
+    inverse4(model16, in.inv);
+    // HittableList::BoundingBox over the prototype's objects (R/src/Core/Hittable.h:298-313), then its eight
+    // corners under the model matrix
+    Box3 ob = objectBox(p.objs[0]);
+    for (size_t i = 1; i < p.objs.size(); i++) ob = unionBox(ob, objectBox(p.objs[i]));
+    for (int c = 0; c < 8; c++) {
+        const float corner[3] = {(c & 1) ? ob.mx[0] : ob.mn[0], (c & 2) ? ob.mx[1] : ob.mn[1], (c & 4) ? ob.mx[2] : ob.mn[2]};
+        float w[3];
+        mulPoint(model16, corner, 1.0f, w);
+        for (int k = 0; k < 3; k++) {
+            if (c == 0 || w[k] < in.box.mn[k]) in.box.mn[k] = w[k];
+            if (c == 0 || w[k] > in.box.mx[k]) in.box.mx[k] = w[k];
+        }
+    }
+    instances.push_back(in);
+    place({Obj::INSTANCE, (int)instances.size() - 1});
+    return (int)instances.size() - 1;
 }
 
 int Scene::beginGroup(bool boxed, const float* box6) {
@@ -405,6 +449,7 @@ Box3 Scene::objectBox(const Obj& o) const {
         return b;
     }
     if (o.kind == Obj::TRIANGLE) return triangleBox(triangles[o.id]);
+    if (o.kind == Obj::INSTANCE) return instances[o.id].box;
     return composites[o.id].box;
 }
 
@@ -1046,11 +1091,18 @@ int Scene::newEntry(const Box3* box) {
 void Scene::emitObjects(const std::vector<Obj>& objs, int parent_entry) {
     bool can_attach = parent_entry >= 0;
     size_t i = 0;
+    auto isPrimitive = [](const Obj& o) { return o.kind == Obj::SPHERE || o.kind == Obj::TRIANGLE; };
     while (i < objs.size()) {
-        if (objs[i].kind != Obj::COMPOSITE) {
+        if (objs[i].kind == Obj::INSTANCE) {
+            // an entry of its own: the placement's box, the instance's number where a leaf run's start would be
+            const int e = newEntry(&instances[objs[i].id].box);
+            flat.nodes[(size_t)e * 8 + 3] |= kNodeInstance;
+            flat.nodes[(size_t)e * 8 + 7] = (uint32_t)objs[i].id;
+            i++;
+        } else if (isPrimitive(objs[i])) {
             size_t j = i;
             uint32_t first = (uint32_t)flat.prim_refs.size();
-            while (j < objs.size() && objs[j].kind != Obj::COMPOSITE) {
+            while (j < objs.size() && isPrimitive(objs[j])) {
                 flat.prim_refs.push_back((uint32_t)objs[j].id | (objs[j].kind == Obj::TRIANGLE ? kRefTriangle : 0u));
                 j++;
             }
@@ -1104,6 +1156,17 @@ void Scene::flatten() {
     // An empty world (HittableList::Hit over no objects: every ray misses) is one entry without a
     // box test and without a leaf run, so the walks have something to read.
     if (flat.nodes.empty()) newEntry(nullptr);
+    flat.n_world_nodes = (int)(flat.nodes.size() / 8);
+    flat.proto_range.clear();
+    if (!instances.empty()) {
+        // the prototypes' entries follow the world's; each is walked from its first entry to its last by the
+        // rays that enter one of its placements
+        for (const Prototype& p : prototypes) {
+            flat.proto_range.push_back((int32_t)(flat.nodes.size() / 8));
+            emitObjects(p.objs, -1);
+            flat.proto_range.push_back((int32_t)(flat.nodes.size() / 8));
+        }
+    }
     buildFastStructure();
     flat.valid = true;
 }

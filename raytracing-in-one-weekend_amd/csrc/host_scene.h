@@ -15,8 +15,8 @@ struct Box3 {
 
 // One entry of HittableList::objects (R/src/Core/Hittable.h:315): a primitive or a composite.
 struct Obj {
-    enum Kind : int { SPHERE = 0, TRIANGLE = 1, COMPOSITE = 2 } kind;
-    int id;  // sphere id, triangle id, or index into Scene::composites
+    enum Kind : int { SPHERE = 0, TRIANGLE = 1, COMPOSITE = 2, INSTANCE = 3 } kind;
+    int id;  // sphere id, triangle id, index into Scene::composites, or index into Scene::instances
 };
 
 // A node of a built BVH (R/src/AccelerationStructures/Bvh.h:13-100).
@@ -33,6 +33,21 @@ struct Composite {
     std::vector<Obj> objs;   // MESH / LIST children in order
     std::vector<BvhNode> nodes;  // BVH only
     int root = -1;
+};
+
+// Instancing (opt-in; the reference has none: it bakes every placement into world-space triangles,
+// R/src/Core/Mesh.cpp:106-208).  A prototype is a list of objects in object space that is not in the world
+// itself; an instance places it with a model matrix.  Hit semantics are those of the CPU oracle's Instance
+// class: the placement's world-space box, the ray taken into object space (direction not normalised, so hit
+// distances are the same numbers in both spaces), the prototype's own Hit, and the normal brought back
+// through mat3(transpose(inverse(M))) and normalised.
+struct Prototype {
+    std::vector<Obj> objs;
+};
+struct Instance {
+    int prototype;
+    float model[16], inv[16];  // column-major
+    Box3 box;                  // of the prototype's box corners under `model`
 };
 
 struct HostMaterial {
@@ -103,10 +118,17 @@ struct FlatScene {
     std::vector<int32_t> tri_ord;       // triangle id -> position in prim_refs
     std::vector<int32_t> prim_guard;    // position in prim_refs -> innermost box-tested entry of `nodes` above it, or -1
     std::vector<int32_t> node_outer;    // entry of `nodes` -> nearest enclosing box-tested entry whose box does not contain it, or -1
+    // Scenes with instances: entries [0, n_world_nodes) are the world's; the prototypes' entries follow, prototype p
+    // at [proto_range[2 p], proto_range[2 p + 1]), and an instance is a world entry with kNodeInstance set whose
+    // first_ref word is the instance's number.  Such scenes have no search structure: every ray takes the
+    // reference-order walk.
+    int n_world_nodes = 0;
+    std::vector<int32_t> proto_range;
 };
 
 constexpr uint32_t kNodeNoBox = 1u << 30;     // entry without a box test
-constexpr uint32_t kNodeSkipMask = kNodeNoBox - 1;
+constexpr uint32_t kNodeInstance = 1u << 29;  // entry that stands for an instance
+constexpr uint32_t kNodeSkipMask = kNodeInstance - 1;
 constexpr uint32_t kRefLast = 1u << 31;       // last reference of its leaf run
 constexpr uint32_t kRefTriangle = 1u << 30;
 constexpr uint32_t kRefIdMask = kRefTriangle - 1;
@@ -151,6 +173,12 @@ public:
     // Mesh::Hit (R/src/Core/Mesh.h:13-31) alike.  boxed = false: a plain HittableList.
     int beginGroup(bool boxed, const float* box6);
     int endGroup();
+    // Instancing: objects added between beginPrototype() and endPrototype() form a prototype (returned: its
+    // number) instead of going into the world; addInstance() places one.  -1: misuse (nested definition, an
+    // instance of an unknown or unfinished prototype, an empty prototype).
+    int beginPrototype();
+    int endPrototype();
+    int addInstance(int prototype, const float* model16);
     bool groupsOpen() const { return !open_groups_.empty(); }
     void randomScene();
     void cornellBox();
@@ -167,6 +195,8 @@ public:
     std::vector<HostSphere> spheres;
     std::vector<HostTriangle> triangles;
     std::vector<Composite> composites;
+    std::vector<Prototype> prototypes;
+    std::vector<Instance> instances;
     std::vector<Obj> world;  // Scene::world.objects
     Camera22 camera{};
     float background[3] = {0, 0, 0};
@@ -175,6 +205,7 @@ public:
 
 private:
     std::vector<int> open_groups_;  // composites under construction, innermost last
+    int open_prototype_ = -1;       // prototype under construction
     void place(const Obj& o);       // appends to the innermost open group, or to the world
     int newTriangle(const float* pos9, const float* nrm9, const float* uv6, int mat);
     struct BoxedObj {

@@ -197,9 +197,10 @@ int launch(rt_context* ctx, rt::RenderArgs& a, bool count, const Workspace* fixe
     const int threads = 256;
     const int wavesPerBlock = threads / 64;
     const char* kernel = std::getenv("RT_KERNEL");
-    const bool simple = kernel && std::strcmp(kernel, "simple") == 0;
+    // scenes with instances are rendered by the plain kernel (it walks the two levels; the persistent loop does not)
+    const bool simple = (kernel && std::strcmp(kernel, "simple") == 0 && !fixed) || a.sc.n_instances > 0;
     int blocks;
-    if (simple && !fixed) {
+    if (simple) {
         blocks = (a.n_local_tiles + wavesPerBlock - 1) / wavesPerBlock;
         if (blocks < 1) blocks = 1;
         HIP_TRY(rt::launchRender(a, ctx->use_lds, count, blocks, threads, ctx->stream));
@@ -430,6 +431,26 @@ int rt_scene_end_group(rt_scene* s) {
     if (!s) return fail(RT_ERR_INVALID, "null scene");
     if (s->sc.endGroup() < 0) return fail(RT_ERR_STATE, "rt_scene_end_group() without an open group");
     return RT_OK;
+}
+int rt_scene_begin_prototype(rt_scene* s) {
+    if (!s) return fail(RT_ERR_INVALID, "null scene");
+    const int id = s->sc.beginPrototype();
+    if (id < 0) return fail(RT_ERR_STATE, "a prototype or a group is already open");
+    return id;
+}
+int rt_scene_end_prototype(rt_scene* s) {
+    if (!s) return fail(RT_ERR_INVALID, "null scene");
+    const int id = s->sc.endPrototype();
+    if (id < 0) return fail(RT_ERR_STATE, "rt_scene_end_prototype() without an open prototype, or with a group still open");
+    return id;
+}
+int rt_scene_add_instance(rt_scene* s, int prototype, const float* model16) {
+    if (!s || !model16) return fail(RT_ERR_INVALID, "null argument");
+    for (int i = 0; i < 16; i++)
+        if (!std::isfinite(model16[i])) return fail(RT_ERR_INVALID, "model matrix is not finite");
+    const int id = s->sc.addInstance(prototype, model16);
+    if (id < 0) return fail(RT_ERR_INVALID, "unknown, unfinished or empty prototype (or one that holds an instance itself)");
+    return id;
 }
 int rt_scene_wrap_bvh(rt_scene* s) {
     if (!s) return fail(RT_ERR_INVALID, "null scene");
@@ -666,6 +687,8 @@ int rt_upload_scene(rt_context* ctx, rt_scene* s) {
     HIP_TRY(hipSetDevice(ctx->device));
     rt::Scene& sc = s->sc;
     if (sc.groupsOpen()) return fail(RT_ERR_STATE, "a group is still open (rt_scene_end_group() missing)");
+    if (!sc.instances.empty() && sc.normal_mapping)
+        return fail(RT_ERR_INVALID, "normal mapping is not available for scenes with instances");
     // With a device-side build the host prepares the reference-order arrays, the guard tables and the
     // builder's inputs only; a scene flattened earlier for a device build gets its host-built structure
     // now if this context wants one.
@@ -796,6 +819,20 @@ int rt_upload_scene(rt_context* ctx, rt_scene* s) {
     if ((rc = devUpload(ctx, texDesc, &d.tex_desc))) return rc;
     if ((rc = devUpload(ctx, lut, &d.lut))) return rc;
     d.n_nodes = nNodes;
+    d.n_world_nodes = sc.flat.n_world_nodes;
+    d.n_instances = (int)sc.instances.size();
+    {
+        std::vector<float4> inst(sc.instances.size() * 5);
+        for (size_t i = 0; i < sc.instances.size(); i++) {
+            const rt::Instance& in = sc.instances[i];
+            for (int c = 0; c < 4; c++) inst[5 * i + c] = make_float4(in.inv[4 * c], in.inv[4 * c + 1], in.inv[4 * c + 2], in.inv[4 * c + 3]);
+            const int range[4] = {sc.flat.proto_range[2 * in.prototype], sc.flat.proto_range[2 * in.prototype + 1], 0, 0};
+            float4 f;
+            std::memcpy(&f, range, 16);
+            inst[5 * i + 4] = f;
+        }
+        if ((rc = devUpload(ctx, inst, &d.instances))) return rc;
+    }
     d.n_prim_refs = (int)sc.flat.prim_refs.size();
     d.n_fast_nodes = (int)(fastSrc.size() / 8);
     d.n_fast_refs = (int)sc.flat.fast_refs.size();
@@ -829,7 +866,7 @@ int rt_upload_scene(rt_context* ctx, rt_scene* s) {
         d.fast_oct_stride = stride;
         d.n_fast_refs = (int)sc.flat.world_refs.size();
     }
-    d.force_ref = (ctx->force_ref || hugeCoords) ? 1 : 0;
+    d.force_ref = (ctx->force_ref || hugeCoords || !sc.instances.empty()) ? 1 : 0;
     d.origin_limit = sc.flat.fast_min_pad * 2097152.0f;  // 2^21, see buildFastStructure()
     d.far_spheres = sc.flat.far_spheres;
     d.far_tris = sc.flat.far_tris;
@@ -865,7 +902,7 @@ int rt_upload_scene(rt_context* ctx, rt_scene* s) {
     else
         ctx->lds_refs = all <= kLdsThreeGroups || (part > kLdsThreeGroups && all <= kMaxLdsScene);
     ctx->lds_need = ctx->lds_refs ? all : part;
-    ctx->use_lds = ctx->lds_need <= kMaxLdsScene && rt::ldsWalkEntriesFit(d) && ldsMode != 0;
+    ctx->use_lds = ctx->lds_need <= kMaxLdsScene && rt::ldsWalkEntriesFit(d) && ldsMode != 0 && sc.instances.empty();
     ctx->scene_loaded = true;
     return RT_OK;
 }

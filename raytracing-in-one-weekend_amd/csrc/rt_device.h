@@ -30,6 +30,13 @@ struct DevScene {
     const int4* tex_desc;     // {first texel, width, height, 0}
     const float* lut;         // 256-entry 8-bit -> float map
     int n_nodes, n_prim_refs, n_fast_nodes, n_fast_refs, n_spheres, n_tris, n_mats;
+    // Instancing (opt-in): entries [0, n_world_nodes) of `nodes` are the world's, the prototypes' entries follow;
+    // an instance is a world entry with bit 29 of its skip word set and the instance's number in its first_ref
+    // word.  Five float4 per instance: the inverse model matrix column by column, then {first entry, end entry
+    // of its prototype (ints bit-cast), -, -}.  Scenes with instances are rendered by the plain kernel along the
+    // reference-order entries only.
+    const float4* instances;
+    int n_instances, n_world_nodes;
     int fast_oct_stride;      // > 0: fast_nodes holds 8 direction-ordered copies of this many entries each
     int has_pbr;              // 1: some material is a PBRMaterial
     int has_dielectric;       // 1: some material is a Dielectric

@@ -16,7 +16,8 @@
 namespace rt {
 
 constexpr uint32_t kNoBox = 1u << 30;
-constexpr uint32_t kSkipMask = kNoBox - 1;
+constexpr uint32_t kNodeInstance = 1u << 29;
+constexpr uint32_t kSkipMask = kNodeInstance - 1;
 constexpr uint32_t kRefLast = 1u << 31;
 constexpr uint32_t kRefTri = 1u << 30;
 constexpr uint32_t kRefId = kRefTri - 1;
@@ -342,14 +343,16 @@ __device__ __forceinline__ bool primRoot(const SceneView& sv, uint32_t ref, cons
 // The reference's own update rule: primitives arrive in its visit order and each one is
 // tested against the running closest hit.
 template <bool COUNT>
-__device__ __forceinline__ void primRef(const SceneView& sv, uint32_t ref, const Ray& r, float a, Hit& h, Stats* st) {
+__device__ __forceinline__ bool primRef(const SceneView& sv, uint32_t ref, const Ray& r, float a, Hit& h, Stats* st) {
     float t, u = h.bu, v = h.bv;
     if (primRoot<COUNT>(sv, ref, r, a, h.t, t, u, v, st)) {
         h.t = t;
         h.ref = ref & ~kRefLast;
         h.bu = u;
         h.bv = v;
+        return true;
     }
+    return false;
 }
 
 template <int HAS = S_ALL>
@@ -402,6 +405,101 @@ __device__ __forceinline__ Hit traverseRef(const SceneView& sv, int n_nodes, con
                 do {
                     ref = sv.refs[p++];
                     primRef<COUNT>(sv, ref, r, a, h, st);
+                } while (!(ref & kRefLast));
+            }
+            idx = idx + 1;
+        } else {
+            idx = (int)(w3 & kSkipMask);
+        }
+    }
+    return h;
+}
+
+// ------------------------------------------------------------------ instancing (opt-in; plain kernel only)
+// The reference has no instances: it bakes every placement into world-space triangles
+// (R/src/Core/Mesh.cpp:106-208).  What an instance means here is defined by the CPU oracle's Instance class,
+// which these functions follow expression by expression.
+// The ray in the object space of an instance: origin as a point, direction as a vector (not normalised, so a hit
+// distance is the same number in both spaces).  I = the instance's five float4 (DevScene::instances).
+__device__ __forceinline__ Ray toObjectSpace(const float4* I, const Ray& r) {
+    const float4 c0 = I[0], c1 = I[1], c2 = I[2], c3 = I[3];
+    Ray o;
+    o.o = {(c0.x * r.o.x + c1.x * r.o.y) + (c2.x * r.o.z + c3.x * 1.0f), (c0.y * r.o.x + c1.y * r.o.y) + (c2.y * r.o.z + c3.y * 1.0f),
+           (c0.z * r.o.x + c1.z * r.o.y) + (c2.z * r.o.z + c3.z * 1.0f)};
+    o.d = {(c0.x * r.d.x + c1.x * r.d.y) + c2.x * r.d.z, (c0.y * r.d.x + c1.y * r.d.y) + c2.y * r.d.z,
+           (c0.z * r.d.x + c1.z * r.d.y) + c2.z * r.d.z};
+    return o;
+}
+
+// Entries [begin, end) of the reference-order array (a prototype's), walked like traverseRef() with the running
+// closest hit of the caller.  True if a primitive was accepted.
+template <bool COUNT>
+__device__ __forceinline__ bool walkEntryRange(const SceneView& sv, int begin, int end, const Ray& r, float invx, float invy,
+                                               float invz, float a, Hit& h, Stats* st) {
+    bool accepted = false;
+    int idx = begin;
+    while (idx < end) {
+        const float4 n0 = sv.nodes[2 * idx], n1 = sv.nodes[2 * idx + 1];
+        const uint32_t w3 = fbits(n0.w);
+        const int first = (int)fbits(n1.w);
+        bool pass = true;
+        if (!(w3 & kNoBox)) {
+            if (COUNT) st->v[C_NODE]++;
+            pass = slabPass(n0, n1, r, invx, invy, invz, h.t);
+        }
+        if (pass) {
+            if (first >= 0) {
+                int p = first;
+                uint32_t ref;
+                do {
+                    ref = sv.refs[p++];
+                    accepted = primRef<COUNT>(sv, ref, r, a, h, st) || accepted;
+                } while (!(ref & kRefLast));
+            }
+            idx = idx + 1;
+        } else {
+            idx = (int)(w3 & kSkipMask);
+        }
+    }
+    return accepted;
+}
+
+// mWorld.Hit() for a world that holds instances.  instOut: the instance the closest hit was found through, or -1.
+template <bool COUNT>
+__device__ __forceinline__ Hit traverseInstanced(const DevScene& sc, const SceneView& sv, const Ray& r, float invx, float invy,
+                                                 float invz, float a, int& instOut, Stats* st) {
+    Hit h{__builtin_inff(), kNoHit, 0.0f, 0.0f};
+    instOut = -1;
+    int idx = 0;
+    while (idx < sc.n_world_nodes) {
+        const float4 n0 = sv.nodes[2 * idx], n1 = sv.nodes[2 * idx + 1];
+        const uint32_t w3 = fbits(n0.w);
+        const int first = (int)fbits(n1.w);
+        if (w3 & kNodeInstance) {  // Instance::Hit: its box, then the prototype in object space
+            if (COUNT) st->v[C_NODE]++;
+            if (slabPass(n0, n1, r, invx, invy, invz, h.t)) {
+                const float4* I = sc.instances + 5 * first;
+                const Ray ro = toObjectSpace(I, r);
+                const float4 range = I[4];
+                if (walkEntryRange<COUNT>(sv, (int)fbits(range.x), (int)fbits(range.y), ro, 1.0f / ro.d.x, 1.0f / ro.d.y,
+                                          1.0f / ro.d.z, dot(ro.d, ro.d), h, st))
+                    instOut = first;
+            }
+            idx = idx + 1;
+            continue;
+        }
+        bool pass = true;
+        if (!(w3 & kNoBox)) {
+            if (COUNT) st->v[C_NODE]++;
+            pass = slabPass(n0, n1, r, invx, invy, invz, h.t);
+        }
+        if (pass) {
+            if (first >= 0) {
+                int p = first;
+                uint32_t ref;
+                do {
+                    ref = sv.refs[p++];
+                    if (primRef<COUNT>(sv, ref, r, a, h, st)) instOut = -1;
                 } while (!(ref & kRefLast));
             }
             idx = idx + 1;
@@ -471,10 +569,13 @@ __device__ __forceinline__ bool fastTestUsable(const V3& o, float originLimit, f
 
 // mWorld.Hit(r, 0.001f, infinity, rec) (R/src/Core/Raytracer.cpp:10): search structure first,
 // the reference's own walk when its answer cannot be vouched for.
+// inst: the instance the hit was found through, or -1 (scenes with instances only).
 template <bool COUNT>
-__device__ __forceinline__ Hit closestHit(const DevScene& sc, const SceneView& sv, const Ray& r, Stats* st) {
+__device__ __forceinline__ Hit closestHit(const DevScene& sc, const SceneView& sv, const Ray& r, Stats* st, int& inst) {
     const float invx = 1.0f / r.d.x, invy = 1.0f / r.d.y, invz = 1.0f / r.d.z;
     const float a = dot(r.d, r.d);
+    inst = -1;
+    if (sc.n_instances > 0) return traverseInstanced<COUNT>(sc, sv, r, invx, invy, invz, a, inst, st);
     if (!sc.force_ref &&
         fastTestUsable(r.o, sc.origin_limit, invx, invy, invz, -(r.o.x * invx), -(r.o.y * invy), -(r.o.z * invz))) {
         bool bad = false;
@@ -537,6 +638,22 @@ __device__ __forceinline__ Surface surfaceAt(const DevScene& sc, const SceneView
         s.mat = sv.sphere_mat[id];
         s.tri = -1;
     }
+    return s;
+}
+
+// The hit record of a hit found through an instance (inst >= 0): formed in object space, then the point taken from
+// the world ray and the normal brought back through mat3(transpose(inverse(M))) and normalised (the oracle's
+// Instance::Hit).  Column j of that matrix is row j of the inverse, i.e. its rows are the inverse's columns.
+__device__ __forceinline__ Surface surfaceAtInstanced(const DevScene& sc, const SceneView& sv, const Ray& r, const Hit& h, int inst) {
+    if (inst < 0) return surfaceAt(sc, sv, r, h);
+    const float4* I = sc.instances + 5 * inst;
+    const Ray ro = toObjectSpace(I, r);
+    Surface s = surfaceAt(sc, sv, ro, h);
+    s.p = r.o + h.t * r.d;
+    const float4 c0 = I[0], c1 = I[1], c2 = I[2];
+    const V3 n = s.n;
+    s.n = normalize(V3{(c0.x * n.x + c0.y * n.y) + c0.z * n.z, (c1.x * n.x + c1.y * n.y) + c1.z * n.z,
+                       (c2.x * n.x + c2.y * n.y) + c2.z * n.z});
     return s;
 }
 
@@ -731,13 +848,14 @@ __device__ __forceinline__ V3 rayColor(const DevScene& sc, const SceneView& sv, 
             return throughput * V3{0.0f, 0.0f, 0.0f};
         }
         if (COUNT) st->v[C_RAYS]++;
-        Hit h = closestHit<COUNT>(sc, sv, r, st);
+        int inst;
+        Hit h = closestHit<COUNT>(sc, sv, r, st, inst);
         if (h.ref == kNoHit) {
             if (COUNT) st->v[C_MISS]++;
             return throughput * V3{sc.bg[0], sc.bg[1], sc.bg[2]};
         }
         if (COUNT) st->v[C_HITS]++;
-        Surface s = surfaceAt(sc, sv, r, h);
+        Surface s = surfaceAtInstanced(sc, sv, r, h, inst);
         Ray out;
         V3 atten, emit;
         const float4 m0 = sv.materials[2 * s.mat], m1 = sv.materials[2 * s.mat + 1];
@@ -1762,7 +1880,8 @@ __global__ void __launch_bounds__(256) traceKernel(DevScene sc, int n, const flo
     Ray r;
     r.o = {rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]};
     r.d = {rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]};
-    Hit h = closestHit<false>(sc, sv, r, nullptr);
+    int inst;
+    Hit h = closestHit<false>(sc, sv, r, nullptr, inst);
     if (h.ref == kNoHit) {
         kind[i] = -1;
         id[i] = -1;
@@ -1772,7 +1891,7 @@ __global__ void __launch_bounds__(256) traceKernel(DevScene sc, int n, const flo
         uv[2 * i] = uv[2 * i + 1] = 0.0f;
         return;
     }
-    Surface s = surfaceAt(sc, sv, r, h);
+    Surface s = surfaceAtInstanced(sc, sv, r, h, inst);
     kind[i] = (h.ref & kRefTri) ? 1 : 0;
     id[i] = (int)(h.ref & kRefId);
     t[i] = h.t;

@@ -38,6 +38,9 @@ def lib():
         L.orc_add_triangle.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.orc_add_mesh.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                    C.c_void_p, C.c_int, C.c_int]
+        L.orc_begin_prototype.argtypes = [C.c_void_p]
+        L.orc_end_prototype.argtypes = [C.c_void_p]
+        L.orc_add_instance.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.orc_set_camera.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_float] * 4
         L.orc_get_camera.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_set_background.argtypes = [C.c_void_p] + [C.c_float] * 3
@@ -114,6 +117,18 @@ class OracleScene:
         uv = None if uvs is None else _f32(uvs)
         self.L.orc_add_mesh(self.h, _p(m), pos.size // 3, _p(pos), _p(nrm), _p(uv), idx.size // 3, _p(idx), material,
                             max_depth)
+
+    def begin_prototype(self):
+        return self.L.orc_begin_prototype(self.h)
+
+    def end_prototype(self):
+        return self.L.orc_end_prototype(self.h)
+
+    def add_instance(self, prototype, model):
+        m = _f32(model)
+        rc = self.L.orc_add_instance(self.h, prototype, _p(m))
+        assert rc >= 0
+        return rc
 
     def random_scene(self):
         self.L.orc_scene_random(self.h)
