@@ -382,7 +382,8 @@ class Context:
         _check(lib.rt_set_reference_traversal(self.h, 1 if on else 0))
 
     def set_device_build(self, on):
-        _check(lib.rt_set_device_build(self.h, 1 if on else 0))
+        """True / False: always / never build the search structure on the device; None: for large scenes (the default)."""
+        _check(lib.rt_set_device_build(self.h, -1 if on is None else (1 if on else 0)))
 
     def last_build_ms(self):
         ms = C.c_float()

@@ -6,17 +6,19 @@
 // entries above it.  Which primitive a ray returns is decided by the exact primitive tests and the
 // guard test against the reference's boxes, so any such tree gives the reference's image.
 //
-// Method: a linear BVH.  Padded primitive boxes -> 63-bit Morton codes of their centres -> radix sort
-// (hipCUB) -> one internal node per adjacent pair by the longest-common-prefix construction (Karras,
-// "Maximizing parallelism in the construction of BVHs, octrees and k-d trees", 2012) -> boxes and
-// subtree sizes bottom-up -> entries written in walk order with their skip links.  Internal nodes
-// whose two children are both primitives become one entry with a run of two.  As with the host builder,
-// scenes too large for LDS with at most 2 M entries get the entries eight times over, each copy with
-// every node's children ordered near-to-far for one sign pattern of the ray direction (1 M triangles:
-// 75 -> 60 box tests per ray).  The host builder's other refinement -- leaving out inner nodes whose box
-// has more than half the area of the node above -- was tried here with the parent as the yardstick and
-// dropped: a Morton tree has long chains of nearly equal boxes, which that rule flattens into scans of
-// hundreds of siblings (462 box tests per ray).
+// Method: padded primitive boxes -> 63-bit Morton codes of their centres -> radix sort (hipCUB) -> a binary tree
+// over the sorted primitives -> entries written in walk order with their skip links.  The tree is built bottom-up
+// by locally-ordered clustering (see Ploc below; the default), or top-down by the longest-common-prefix
+// construction (Karras, "Maximizing parallelism in the construction of BVHs, octrees and k-d trees", 2012;
+// RT_DEVICE_TREE=lbvh), which is a third faster to build and costs a quarter more box tests per ray.  Internal
+// nodes whose two children are both primitives become one entry with a run of two.  As with the host builder,
+// scenes too large for LDS with at most 2 M entries get the entries eight times over, each copy with every
+// node's children ordered near-to-far for one sign pattern of the ray direction; a single copy visits the child
+// nearer to the eye first; and inner nodes whose box has more than half the area of the entry above are left
+// out (clustering build only: a Morton-split tree has long chains of nearly equal boxes, and judged against
+// their parents that rule flattened them into scans of hundreds of siblings, 462 box tests per ray).
+// Measured on the vase scenes, host surface-area build = 1: Morton-split 1.55 (1 M triangles) / 1.57 (10 M) of its
+// frame time, clustering 1.27 / 1.23, + left-out entries 1.19 / 1.23, + eye order 1.19 / 1.12; build 9 / 15 ms.
 //
 // Hand-offs between threads of one launch are avoided on purpose: the bottom-up pass runs as one
 // launch per tree level (a node is computed in the launch after both its children were), so every
@@ -27,7 +29,9 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <functional>
+#include <string>
 #include <vector>
 
 #include "rt_device.h"
@@ -128,8 +132,14 @@ struct Tree {
     int* last;
     float4* nbox;             // 2 per internal node
     int* count;               // entries the subtree emits
+    int* lcount;              // primitives below the node
+    int root;                 // the root's internal-node number
+    float* area;              // half the surface area of the node's box (clustering build)
+    float* above;             // the same of the nearest ancestor that has an entry
+    uint8_t* kept;            // 1: the node has an entry of its own; 0: left out, its children stand in its place
     int* stamp;               // number of the fitLevel launch that computed the node; 0 = not yet
-    uint8_t* rfirst;          // bit k: for direction-sign pattern k the right child is visited first
+    uint16_t* rfirst;         // bit k < 8: for direction-sign pattern k the right child is visited first; bit 8: for the
+                              // single copy, whose children go nearer to the eye first (larger box on a tie)
     int* pending;             // [0]: internal nodes still without a box
 };
 
@@ -209,11 +219,188 @@ __global__ void __launch_bounds__(256) fitLevel(Tree t, const float4* pbox, int 
         const float ar = ((k & 1) ? -bmx.x : bmn.x) + ((k & 2) ? -bmx.y : bmn.y) + ((k & 4) ? -bmx.z : bmn.z);
         if (ar < al) mask |= 1u << k;
     }
-    t.rfirst[i] = (uint8_t)mask;
+    t.rfirst[i] = (uint16_t)mask;
     // a node over two primitives is ONE entry with a run of two; otherwise itself plus both subtrees
     t.count[i] = (lc < 0 && rc < 0) ? 1 : 1 + cl + cr;
+    t.lcount[i] = (lc < 0 ? 1 : t.lcount[lc]) + (rc < 0 ? 1 : t.lcount[rc]);
     t.stamp[i] = launch;
     atomicSub(t.pending, 1);
+}
+
+// ---------------------------------------------------------------------------------------
+// Agglomerative build by parallel locally-ordered clustering (Meister and Bittner, "Parallel locally-ordered
+// clustering for bounding volume hierarchy construction", 2018), the default: the Morton-sorted primitives
+// are the first clusters; in every round each cluster looks at its `radius` neighbours to either side in the
+// array for the one whose union with it has the smallest surface area, pairs that chose each other are
+// merged into a new node that takes the place of the first of the two, and the array is compacted.  The
+// comparison key is (area, lower position, higher position), which no two pairs share, so the pair with the
+// smallest key of all always chooses each other and every round merges something.  Trees built this way cost
+// about as many box tests per ray as the host's surface-area build, where the Morton-split tree above costs
+// 1.6 times as many.
+// Like the rest of this file, a round is a sequence of launches: nothing is read that a thread of the same
+// launch may still be writing (a node's children were created by earlier rounds).
+struct Ploc {
+    Tree t;
+    const float4* pbox;
+    const int* cidIn;       // cluster -> child code (>= 0 internal node, < 0 leaf ~sorted position)
+    const float4* cboxIn;   // 2 per cluster
+    int* cidOut;
+    float4* cboxOut;
+    int* nn;                // chosen neighbour per cluster
+    unsigned long long* flags;    // per cluster: (starts a merge) << 32 | (stays in the array)
+    unsigned long long* scanned;  // exclusive sums of `flags`
+    const int* stateIn;     // {clusters, internal nodes created so far}
+    int* stateOut;
+    int radius;
+    int round;
+    int* roundBase;         // roundBase[r]: internal nodes that existed before round r
+    float eye[3];
+    float collapse;
+};
+
+__device__ __forceinline__ float unionArea(const float4& amn, const float4& amx, const float4& bmn, const float4& bmx) {
+    const float dx = fmaxf(amx.x, bmx.x) - fminf(amn.x, bmn.x), dy = fmaxf(amx.y, bmx.y) - fminf(amn.y, bmn.y),
+                dz = fmaxf(amx.z, bmx.z) - fminf(amn.z, bmn.z);
+    return dx * dy + dy * dz + dz * dx;
+}
+
+__global__ void __launch_bounds__(256) plocInit(Tree t, const float4* pbox, int* cid, float4* cbox, int* state) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) {
+        state[0] = t.n;
+        state[1] = 0;
+    }
+    if (i >= t.n) return;
+    const size_t p = t.order[i];
+    cid[i] = ~i;
+    cbox[2 * (size_t)i] = pbox[2 * p];
+    cbox[2 * (size_t)i + 1] = pbox[2 * p + 1];
+    t.parent[(t.n - 1) + i] = -1;
+}
+
+__global__ void __launch_bounds__(256) plocNearest(Ploc a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int m = a.stateIn[0];
+    if (i >= m) return;
+    const float4 mn = a.cboxIn[2 * (size_t)i], mx = a.cboxIn[2 * (size_t)i + 1];
+    const int lo = i - a.radius < 0 ? 0 : i - a.radius, hi = i + a.radius > m - 1 ? m - 1 : i + a.radius;
+    float best = __builtin_inff();
+    int bj = -1;
+    for (int j = lo; j <= hi; j++) {
+        if (j == i) continue;
+        const float d = unionArea(mn, mx, a.cboxIn[2 * (size_t)j], a.cboxIn[2 * (size_t)j + 1]);
+        // key (d, lower position, higher position); j runs upwards, so among equal areas the first j below i has
+        // the smallest key of those below, and any j below i beats every j above it
+        if (d < best || bj < 0) {
+            best = d;
+            bj = j;
+        }
+    }
+    a.nn[i] = bj;
+}
+
+__global__ void __launch_bounds__(256) plocFlags(Ploc a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int m = a.stateIn[0];
+    if (i >= m) return;
+    const int j = a.nn[i];
+    const bool mutual = j >= 0 && a.nn[j] == i;
+    const unsigned long long leader = mutual && i < j ? 1ull : 0ull, stays = mutual && i > j ? 0ull : 1ull;
+    a.flags[i] = (leader << 32) | stays;
+}
+
+__global__ void __launch_bounds__(256) plocMerge(Ploc a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int m = a.stateIn[0];
+    if (i >= m) return;
+    const Tree& t = a.t;
+    const unsigned long long f = a.flags[i], sc = a.scanned[i];
+    if (i == m - 1) {
+        a.stateOut[0] = (int)(unsigned)(sc & 0xFFFFFFFFull) + (int)(unsigned)(f & 0xFFFFFFFFull);
+        a.stateOut[1] = a.stateIn[1] + (int)(unsigned)(sc >> 32) + (int)(unsigned)(f >> 32);
+        a.roundBase[a.round] = a.stateIn[1];
+        a.roundBase[a.round + 1] = a.stateOut[1];
+    }
+    if (!(f & 0xFFFFFFFFull)) return;  // merged into its partner's place
+    const size_t pos = (size_t)(sc & 0xFFFFFFFFull);
+    if (!(f >> 32)) {
+        a.cidOut[pos] = a.cidIn[i];
+        a.cboxOut[2 * pos] = a.cboxIn[2 * (size_t)i];
+        a.cboxOut[2 * pos + 1] = a.cboxIn[2 * (size_t)i + 1];
+        return;
+    }
+    const int j = a.nn[i];
+    const int node = a.stateIn[1] + (int)(unsigned)(sc >> 32);
+    const int lc = a.cidIn[i], rc = a.cidIn[j];
+    const float4 amn = a.cboxIn[2 * (size_t)i], amx = a.cboxIn[2 * (size_t)i + 1];
+    const float4 bmn = a.cboxIn[2 * (size_t)j], bmx = a.cboxIn[2 * (size_t)j + 1];
+    const float4 mn = make_float4(fminf(amn.x, bmn.x), fminf(amn.y, bmn.y), fminf(amn.z, bmn.z), 0.f);
+    const float4 mx = make_float4(fmaxf(amx.x, bmx.x), fmaxf(amx.y, bmx.y), fmaxf(amx.z, bmx.z), 0.f);
+    t.left[node] = lc;
+    t.right[node] = rc;
+    t.parent[lc < 0 ? (t.n - 1) + ~lc : lc] = node;
+    t.parent[rc < 0 ? (t.n - 1) + ~rc : rc] = node;
+    t.parent[node] = -1;  // until a later round gives it one
+    t.nbox[2 * (size_t)node] = mn;
+    t.nbox[2 * (size_t)node + 1] = mx;
+    unsigned mask = 0;  // for every sign pattern of the ray direction: is the right child's box entered first?
+    for (int k = 0; k < 8; k++) {
+        const float al = ((k & 1) ? -amx.x : amn.x) + ((k & 2) ? -amx.y : amn.y) + ((k & 4) ? -amx.z : amn.z);
+        const float ar = ((k & 1) ? -bmx.x : bmn.x) + ((k & 2) ? -bmx.y : bmn.y) + ((k & 4) ? -bmx.z : bmn.z);
+        if (ar < al) mask |= 1u << k;
+    }
+    {
+        // the single copy: the child whose box is nearer to the eye first, the larger one on a tie (host builder's rule)
+        auto eyeDist2 = [&](const float4& bn, const float4& bx) {
+            const float dx = fmaxf(0.0f, fmaxf(bn.x - a.eye[0], a.eye[0] - bx.x)), dy = fmaxf(0.0f, fmaxf(bn.y - a.eye[1], a.eye[1] - bx.y)),
+                        dz = fmaxf(0.0f, fmaxf(bn.z - a.eye[2], a.eye[2] - bx.z));
+            return dx * dx + dy * dy + dz * dz;
+        };
+        auto halfArea = [](const float4& bn, const float4& bx) {
+            const float dx = bx.x - bn.x, dy = bx.y - bn.y, dz = bx.z - bn.z;
+            return dx * dy + dy * dz + dz * dx;
+        };
+        const float dl = eyeDist2(amn, amx), dr = eyeDist2(bmn, bmx);
+        if (dl == dr ? halfArea(amn, amx) < halfArea(bmn, bmx) : dl > dr) mask |= 1u << 8;
+    }
+    t.rfirst[node] = (uint16_t)mask;
+    const int cl = lc < 0 ? 1 : t.count[lc], cr = rc < 0 ? 1 : t.count[rc];
+    t.count[node] = (lc < 0 && rc < 0) ? 1 : 1 + cl + cr;
+    t.lcount[node] = (lc < 0 ? 1 : t.lcount[lc]) + (rc < 0 ? 1 : t.lcount[rc]);
+    {
+        const float dx = mx.x - mn.x, dy = mx.y - mn.y, dz = mx.z - mn.z;
+        t.area[node] = dx * dy + dy * dz + dz * dx;
+    }
+    a.cidOut[pos] = node;
+    a.cboxOut[2 * pos] = mn;
+    a.cboxOut[2 * pos + 1] = mx;
+}
+
+// Which nodes get an entry (the host builder's rule, fast_bvh.cpp: Emission::gather): a node over two subtrees whose
+// box has more than half the area of the entry above it would pass nearly every ray that entry passes, so it is
+// left out and its children are tested in its place.  "The entry above" is the nearest ancestor that HAS an entry,
+// so the rule cannot flatten a long chain of nearly equal boxes into one scan: after a few levels the area has
+// halved.  Parents are decided before children: one launch per round of the build, last round first.
+__global__ void __launch_bounds__(256) keptOfRound(Tree t, int lo, int hi, float collapse) {
+    const int i = lo + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= hi) return;
+    const int p = t.parent[i];
+    const float a = t.area[i];
+    const float abv = p < 0 ? a : (t.kept[p] ? t.area[p] : t.above[p]);
+    const bool twig = t.left[i] < 0 && t.right[i] < 0;
+    t.above[i] = abv;
+    t.kept[i] = (twig || !(a > collapse * abv)) ? 1 : 0;
+}
+// Entries below and including each node, children before parents: one launch per round, first round first.
+__global__ void __launch_bounds__(256) countOfRound(Tree t, int lo, int hi) {
+    const int i = lo + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= hi) return;
+    const int lc = t.left[i], rc = t.right[i];
+    if (lc < 0 && rc < 0) {
+        t.count[i] = 1;
+        return;
+    }
+    t.count[i] = (t.kept[i] ? 1 : 0) + (lc < 0 ? 1 : t.count[lc]) + (rc < 0 ? 1 : t.count[rc]);
 }
 
 struct EmitArgs {
@@ -241,13 +428,33 @@ __device__ __forceinline__ void walkIndex(const Tree& t, int slot, int copies, i
         const int rslot = rc < 0 ? (t.n - 1) + ~rc : rc;
         const bool isRight = rslot == cur;
         const int sibling = emitted(t, isRight ? lc : rc);
-        const unsigned mask = copies == 8 ? t.rfirst[p] : 0u;
+        const unsigned mask = copies == 8 ? t.rfirst[p] : (unsigned)(t.rfirst[p] >> 8);
+        const int own = t.kept[p] ? 1 : 0;  // an ancestor that was left out has no entry before its children's
         for (int k = 0; k < copies; k++) {
             const bool rightFirst = (mask >> k) & 1u;
-            idx[k] += 1 + ((isRight != rightFirst) ? sibling : 0);
+            idx[k] += own + ((isRight != rightFirst) ? sibling : 0);
         }
         cur = p;
     }
+}
+
+// Position of a primitive in the leaf references: its rank among the primitives in walk order.  The runs are shared
+// by all eight copies, whose walks differ, so with copies they follow the walk that takes left children first; the
+// single copy's runs follow its own walk (nearer to the eye first).
+__device__ __forceinline__ int leafIndex(const Tree& t, int slot, int copies) {
+    int idx = 0, cur = slot;
+    for (int p = t.parent[cur]; p >= 0; p = t.parent[cur]) {
+        const int lc = t.left[p], rc = t.right[p];
+        const int rslot = rc < 0 ? (t.n - 1) + ~rc : rc;
+        const bool isRight = rslot == cur;
+        const bool rightFirst = copies == 1 && ((t.rfirst[p] >> 8) & 1u);
+        if (isRight != rightFirst) {
+            const int sib = isRight ? lc : rc;
+            idx += sib < 0 ? 1 : t.lcount[sib];
+        }
+        cur = p;
+    }
+    return idx;
 }
 
 __device__ __forceinline__ void writeEntry(const EmitArgs& e, const int idx[8], float4 mn, float4 mx, int count, int firstRef) {
@@ -268,23 +475,26 @@ __global__ void __launch_bounds__(256) emitEntries(EmitArgs e) {
     const Tree& t = e.t;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     int idx[8];
-    if (i < t.n - 1) {  // internal node i
+    if (i < t.n - 1 && t.kept[i]) {  // internal node i
         const bool twig = t.left[i] < 0 && t.right[i] < 0;
         walkIndex(t, i, e.copies, idx);
-        writeEntry(e, idx, t.nbox[2 * (size_t)i], t.nbox[2 * (size_t)i + 1], t.count[i], twig ? t.first[i] : -1);
+        writeEntry(e, idx, t.nbox[2 * (size_t)i], t.nbox[2 * (size_t)i + 1], t.count[i],
+                   twig ? leafIndex(t, (t.n - 1) + ~((e.copies == 1 && ((t.rfirst[i] >> 8) & 1u)) ? t.right[i] : t.left[i]), e.copies) : -1);
     }
     if (i < t.n) {      // leaf at sorted position i
         const size_t p = t.order[i];
         const int par = t.n > 1 ? t.parent[(t.n - 1) + i] : -1;
         const bool underTwig = par >= 0 && t.left[par] < 0 && t.right[par] < 0;
-        const bool lastOfRun = !underTwig || i == t.last[par];
-        e.out_refs[i] = e.refs[p] | (lastOfRun ? kLast : 0u);
+        const bool twigRightFirst = underTwig && e.copies == 1 && ((t.rfirst[par] >> 8) & 1u);
+        const bool lastOfRun = !underTwig || ~(twigRightFirst ? t.left[par] : t.right[par]) == i;
+        const int at = t.n > 1 ? leafIndex(t, (t.n - 1) + i, e.copies) : 0;
+        e.out_refs[at] = e.refs[p] | (lastOfRun ? kLast : 0u);
         if (!underTwig) {  // an entry of its own with a run of one
             if (t.n > 1)
                 walkIndex(t, (t.n - 1) + i, e.copies, idx);
             else
                 for (int k = 0; k < 8; k++) idx[k] = 0;
-            writeEntry(e, idx, e.pbox[2 * p], e.pbox[2 * p + 1], 1, i);
+            writeEntry(e, idx, e.pbox[2 * p], e.pbox[2 * p + 1], 1, at);
         }
     }
     if (e.copies == 8 && i < 8) {
@@ -305,7 +515,7 @@ __global__ void __launch_bounds__(256) emitEntries(EmitArgs e) {
 // want_copies(entries of one copy) decides whether the eight direction-ordered copies are written; *stride
 // comes back 0 (one copy) or entries + 1.
 hipError_t buildSearchStructureOnDevice(int n, const uint32_t* d_refs, const float4* d_spheres, const float4* d_tris,
-                                        float pad_floor, float far_typical, const float cmin[3], const float cmax[3], hipStream_t stream,
+                                        float pad_floor, float far_typical, const float cmin[3], const float cmax[3], const float eye[3], hipStream_t stream,
                                         const std::function<bool(int)>& want_copies, float4** entries, uint32_t** out_refs,
                                         int* n_entries, int* stride, float* build_ms) {
     *stride = 0;
@@ -325,7 +535,22 @@ hipError_t buildSearchStructureOnDevice(int n, const uint32_t* d_refs, const flo
     uint64_t *keysA = nullptr, *keysB = nullptr;
     uint32_t *ordA = nullptr, *ordB = nullptr;
     int *left = nullptr, *right = nullptr, *parent = nullptr, *first = nullptr, *last = nullptr, *count = nullptr, *stamp = nullptr, *pending = nullptr;
-    uint8_t* rfirst = nullptr;
+    int *lcount = nullptr, *cidA = nullptr, *cidB = nullptr, *nn = nullptr, *state = nullptr;
+    float4 *cboxA = nullptr, *cboxB = nullptr;
+    unsigned long long *flags = nullptr, *scanned = nullptr;
+    float *area = nullptr, *above = nullptr;
+    uint8_t* kept = nullptr;
+    int* roundBase = nullptr;
+    constexpr int kMaxRounds = 4096;
+    void* scanTemp = nullptr;
+    size_t scanBytes = 0;
+    // RT_DEVICE_TREE=lbvh: the Morton-split tree (Karras) instead of the clustering build; RT_PLOC_RADIUS: how far
+    // to either side a cluster looks for its partner
+    const char* treeEnv = std::getenv("RT_DEVICE_TREE");
+    const bool ploc = !(treeEnv && std::string(treeEnv) == "lbvh");
+    const char* radiusEnv = std::getenv("RT_PLOC_RADIUS");
+    const int radius = std::max(1, std::min(64, radiusEnv ? std::atoi(radiusEnv) : 10));
+    uint16_t* rfirst = nullptr;
     void* sortTemp = nullptr;
     size_t sortBytes = 0;
     alloc((void**)&pbox, N * 32);
@@ -340,8 +565,26 @@ hipError_t buildSearchStructureOnDevice(int n, const uint32_t* d_refs, const flo
     alloc((void**)&first, N * 4);
     alloc((void**)&last, N * 4);
     alloc((void**)&count, N * 4);
+    alloc((void**)&lcount, N * 4);
+    alloc((void**)&kept, N);
+    if (e == hipSuccess) e = hipMemsetAsync(kept, 1, N, stream);  // the Morton-split tree keeps every node
+    if (ploc) {
+        alloc((void**)&area, N * 4);
+        alloc((void**)&above, N * 4);
+        alloc((void**)&roundBase, (kMaxRounds + 2) * sizeof(int));
+        alloc((void**)&cidA, N * 4);
+        alloc((void**)&cidB, N * 4);
+        alloc((void**)&cboxA, N * 32);
+        alloc((void**)&cboxB, N * 32);
+        alloc((void**)&nn, N * 4);
+        alloc((void**)&flags, N * 8);
+        alloc((void**)&scanned, N * 8);
+        alloc((void**)&state, 64);
+        if (e == hipSuccess) e = hipcub::DeviceScan::ExclusiveSum(nullptr, scanBytes, flags, scanned, n, stream);
+        alloc(&scanTemp, scanBytes);
+    }
     alloc((void**)&stamp, N * 4);
-    alloc((void**)&rfirst, N);
+    alloc((void**)&rfirst, N * 2);
     alloc((void**)&pending, 256);
     if (e == hipSuccess) e = hipcub::DeviceRadixSort::SortPairs(nullptr, sortBytes, keysA, keysB, ordA, ordB, n, 0, 63, stream);
     alloc(&sortTemp, sortBytes);
@@ -373,9 +616,62 @@ hipError_t buildSearchStructureOnDevice(int n, const uint32_t* d_refs, const flo
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipcub::DeviceRadixSort::SortPairs(sortTemp, sortBytes, keysA, keysB, ordA, ordB, n, 0, 63, stream);
-    Tree t{n, keysB, ordB, left, right, parent, first, last, nbox, count, stamp, rfirst, pending};
+    Tree t{n, keysB, ordB, left, right, parent, first, last, nbox, count, lcount, 0, area, above, kept, stamp, rfirst, pending};
     int total = 1;
-    if (e == hipSuccess && n > 1) {
+    if (e == hipSuccess && n > 1 && ploc) {
+        t.root = n - 2;  // nodes are numbered as they are created, and the root is created last
+        plocInit<<<blocks, 256, 0, stream>>>(t, pbox, cidA, cboxA, state);
+        e = hipGetLastError();
+        int m = n;       // clusters left (an upper bound between the read-backs)
+        int* stateIn = state;
+        int* stateOut = state + 8;
+        int rounds = 0;
+        for (int round = 0; e == hipSuccess && m > 1; round++, rounds++) {
+            if (round >= kMaxRounds) {
+                e = hipErrorUnknown;  // every round merges at least one pair
+                break;
+            }
+            const int grid = (m + 255) / 256;
+            Ploc a{t, pbox, cidA, cboxA, cidB, cboxB, nn, flags, scanned, stateIn, stateOut, radius, round, roundBase, {eye[0], eye[1], eye[2]}, 0.0f};
+            plocNearest<<<grid, 256, 0, stream>>>(a);
+            plocFlags<<<grid, 256, 0, stream>>>(a);
+            e = hipGetLastError();
+            if (e == hipSuccess) e = hipcub::DeviceScan::ExclusiveSum(scanTemp, scanBytes, flags, scanned, m, stream);
+            if (e == hipSuccess) {
+                plocMerge<<<grid, 256, 0, stream>>>(a);
+                e = hipGetLastError();
+            }
+            std::swap(cidA, cidB);
+            std::swap(cboxA, cboxB);
+            std::swap(stateIn, stateOut);
+            if ((round & 3) == 3 || m <= 4096) {  // how many are left, every fourth round (every round near the end)
+                int st[2] = {0, 0};
+                if (e == hipSuccess) e = hipMemcpyAsync(st, stateIn, sizeof st, hipMemcpyDeviceToHost, stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(stream);
+                m = st[0];
+            }
+        }
+        // which nodes have entries (parents first), then the entries per subtree (children first)
+        std::vector<int> base((size_t)rounds + 1, 0);
+        if (e == hipSuccess && rounds > 0) e = hipMemcpyAsync(base.data(), roundBase, base.size() * sizeof(int), hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        // RT_DEVICE_COLLAPSE: the area ratio above which an inner node is left out (0 = keep every node)
+        const float collapse = std::getenv("RT_DEVICE_COLLAPSE") ? (float)std::atof(std::getenv("RT_DEVICE_COLLAPSE")) : 0.5f;
+        if (collapse > 0.0f) {
+            for (int r = rounds - 1; r >= 0 && e == hipSuccess; r--) {
+                const int lo = base[(size_t)r], hi = base[(size_t)r + 1];
+                if (hi > lo) keptOfRound<<<(hi - lo + 255) / 256, 256, 0, stream>>>(t, lo, hi, collapse);
+                e = hipGetLastError();
+            }
+            for (int r = 0; r < rounds && e == hipSuccess; r++) {
+                const int lo = base[(size_t)r], hi = base[(size_t)r + 1];
+                if (hi > lo) countOfRound<<<(hi - lo + 255) / 256, 256, 0, stream>>>(t, lo, hi);
+                e = hipGetLastError();
+            }
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(&total, count + t.root, sizeof total, hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    } else if (e == hipSuccess && n > 1) {
         int todo = n - 1;
         e = hipMemcpyAsync(pending, &todo, sizeof todo, hipMemcpyHostToDevice, stream);
         if (e == hipSuccess) {

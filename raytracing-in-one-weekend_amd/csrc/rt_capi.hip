@@ -30,7 +30,7 @@ hipError_t launchScatter(const DevScene& sc, int n, const int* mat, const float*
                          const int* front, const float* uv, const unsigned int* key4, float* atten, float* rayOut,
                          int* alive, unsigned int* counterOut, hipStream_t stream);
 hipError_t buildSearchStructureOnDevice(int n, const uint32_t* d_refs, const float4* d_spheres, const float4* d_tris,
-                                        float pad_floor, float far_typical, const float cmin[3], const float cmax[3], hipStream_t stream,
+                                        float pad_floor, float far_typical, const float cmin[3], const float cmax[3], const float eye[3], hipStream_t stream,
                                         const std::function<bool(int)>& want_copies, float4** entries, uint32_t** out_refs,
                                         int* n_entries, int* stride, float* build_ms);
 hipError_t launchReflectance(int n, const float* cosine, const float* refIdx, float* out, hipStream_t stream);
@@ -72,7 +72,7 @@ struct rt_context {
     size_t colors_cap = 0;           // in samples
     float4* records = nullptr;       // path records of the two-pass launches, three planes of records_cap (grown on demand)
     size_t records_cap = 0;          // in samples
-    bool device_build = false;  // rt_upload_scene() builds the search structure on the device
+    int device_build = -1;      // rt_upload_scene() builds the search structure on the device: 1 always, 0 never, -1 for large scenes
     float build_ms = 0.0f;      // device time of the last such build
     void* resolved = nullptr;  // row-major image the read-out calls resolve into (grown on demand, kept)
     size_t resolved_cap = 0;   // in bytes
@@ -646,7 +646,7 @@ int rt_set_stream(rt_context* ctx, void* hip_stream) {
 
 int rt_set_device_build(rt_context* ctx, int on) {
     if (!ctx) return fail(RT_ERR_INVALID, "null context");
-    ctx->device_build = on != 0;
+    ctx->device_build = on < 0 ? -1 : (on != 0 ? 1 : 0);
     return RT_OK;
 }
 
@@ -692,11 +692,19 @@ int rt_upload_scene(rt_context* ctx, rt_scene* s) {
     // With a device-side build the host prepares the reference-order arrays, the guard tables and the
     // builder's inputs only; a scene flattened earlier for a device build gets its host-built structure
     // now if this context wants one.
-    sc.flat.defer_search_build = ctx->device_build;
+    // Left to itself (-1) the context builds on the device from RT_DEVICE_BUILD_MIN primitives up (default 2 M: there the
+    // host build takes seconds and the device-built tree costs about an eighth more per frame; at 1 M it is 0.6 s
+    // against a fifth more), unless the scene already carries a host-built structure from an earlier flatten.
+    ctx->build_ms = 0.0f;
+    const bool hostBuiltAlready = sc.flat.valid && !sc.flat.fast_stale && !sc.flat.fast_nodes.empty();
+    const size_t autoMin = (size_t)std::max(1, envInt("RT_DEVICE_BUILD_MIN", 2000000));
+    const bool wantDevice = ctx->device_build == 1 ||
+                            (ctx->device_build < 0 && !hostBuiltAlready && sc.spheres.size() + sc.triangles.size() >= autoMin);
+    sc.flat.defer_search_build = wantDevice;
     sc.flatten();
-    if (!ctx->device_build && sc.flat.fast_nodes.empty()) sc.buildFastStructure();
+    if (!wantDevice && sc.flat.fast_nodes.empty()) sc.buildFastStructure();
     sc.flat.defer_search_build = false;
-    const bool deviceBuild = ctx->device_build && !sc.flat.world_refs.empty();
+    const bool deviceBuild = wantDevice && !sc.flat.world_refs.empty();
     for (const auto& m : sc.materials)
         if (m.kind == RT_MAT_PBR && (m.tex_d < 0 || m.tex_d >= (int)sc.textures.size()))
             return fail(RT_ERR_INVALID, "PBR material without a diffuse texture");
@@ -856,7 +864,7 @@ int rt_upload_scene(rt_context* ctx, rt_scene* s) {
             return !fitsLds && nE <= (1 << 21) && envInt("RT_OCTANTS", 1) != 0;
         };
         HIP_TRY(rt::buildSearchStructureOnDevice((int)sc.flat.world_refs.size(), dWorld, d.spheres, d.tri_isect,
-                                                 sc.flat.pad_floor, sc.flat.far_typical, sc.flat.centroid_min, sc.flat.centroid_max, ctx->stream,
+                                                 sc.flat.pad_floor, sc.flat.far_typical, sc.flat.centroid_min, sc.flat.centroid_max, sc.camera.origin, ctx->stream,
                                                  wantCopies, &entries, &refs, &nEntries, &stride, &ctx->build_ms));
         ctx->scene_allocs.push_back(entries);
         ctx->scene_allocs.push_back(refs);
