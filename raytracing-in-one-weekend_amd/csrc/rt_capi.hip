@@ -232,12 +232,12 @@ int launch(rt_context* ctx, rt::RenderArgs& a, bool count, const Workspace* fixe
                                           std::to_string(fixed->colors_cap) + " slots");
         budget = std::min(budget, fixed->colors_cap * sizeof(rt::Radiance));
     }
-    // RT_TWO_PASS=1: two passes (primaryPass, then the loop over its path records) for scenes whose tables are in
-    // LDS: the camera rays of a tile are walked together, a full wave at a time.  Off by default: measured on the
-    // bench workload it is level with the single pass (20.1 against 19.95 ms), for 48 bytes of records per pixel
-    // sample of a launch (RT_RECORDS_MB, default 6400, bounds them).  Never for the fixed-scratch entry point or
-    // with the reference-order walk forced.
-    const bool twoPass = !fixed && ctx->use_lds && !a.sc.force_ref && a.max_depth >= 1 && envInt("RT_TWO_PASS", 0) != 0;
+    // Two passes (primaryPass, then the loop over its path records) for scenes whose tables are in LDS: the camera
+    // rays of a tile are walked together, a full wave at a time, and the loop's SHADE and NEWPATH become one phase
+    // (bench workload 18.7 ms against 19.95 for the single pass; RT_TWO_PASS=0 selects that).  Costs 48 bytes of
+    // records per pixel sample of a launch (RT_RECORDS_MB, default 6400, bounds them).  Never for the fixed-scratch
+    // entry point or with the reference-order walk forced.
+    const bool twoPass = !fixed && ctx->use_lds && !a.sc.force_ref && a.max_depth >= 1 && envInt("RT_TWO_PASS", 1) != 0;
     constexpr size_t kRecordBytes = 48;
     if (twoPass) budget = std::min(budget, ((size_t)std::max(16, envInt("RT_RECORDS_MB", 6400)) << 20) / kRecordBytes * sizeof(rt::Radiance));
     size_t maxSamples = std::max<size_t>(1, budget / ((size_t)nSlots * sizeof(rt::Radiance)));

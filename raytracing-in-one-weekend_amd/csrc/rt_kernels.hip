@@ -1074,6 +1074,11 @@ __device__ __forceinline__ int popc64(unsigned long long m) {
 template <bool LDS, bool COUNT, bool TIME = false, int HAS = S_ALL, bool NMAP = false, bool SPLIT = false>
 __global__ void __launch_bounds__(WF_MAX_THREADS, LDS ? WF_WAVES_LDS : WF_WAVES_GLOBAL) renderWavefront(RenderArgs a) {
     const DevScene& sc = a.sc;
+    // Second pass of a two-pass launch: SHADE and NEWPATH run as ONE phase.  Taking the next record is a handful of
+    // loads there, both end with a new ray being set up, and a lane whose path ends in SHADE takes its next record in
+    // the same turn of the loop (two-pass 20.1 -> 18.7 ms; with camera rays in NEWPATH the merged phase loses:
+    // single pass 20.0 -> 20.4 ms).
+    constexpr bool MERGE = SPLIT;
     // a first pass that was cut short has not written all its records: nothing to go on with
     if (SPLIT && a.queue[1]) return;
     fillCounterLut<(HAS & S_PBR) != 0>(sc.lut);
@@ -1241,7 +1246,19 @@ __global__ void __launch_bounds__(WF_MAX_THREADS, LDS ? WF_WAVES_LDS : WF_WAVES_
         // Pick the operation to run: whichever has the most lanes waiting; shading and path
         // set-up are the costly ones, so they also go as soon as `shadeMin` lanes have piled up.
         int chosen;
-        if (cShade >= shadeMin || cPath >= shadeMin) {
+        if (MERGE) {
+            // SHADE and NEWPATH are one phase (both end with a new ray being set up): lanes waiting for either count together
+            const int cRegen = cShade + cPath;
+            if (cRegen >= shadeMin) {
+                chosen = OP_SHADE;
+            } else {
+                chosen = OP_BOX;
+                int best = cBox;
+                if (cRef > best) { best = cRef; chosen = OP_REFBOX; }
+                if (cPrim > best) { best = cPrim; chosen = OP_PRIM; }
+                if (cRegen > best) { best = cRegen; chosen = OP_SHADE; }
+            }
+        } else if (cShade >= shadeMin || cPath >= shadeMin) {
             chosen = cShade >= cPath ? OP_SHADE : OP_NEWPATH;
         } else {
             chosen = OP_BOX;
@@ -1256,7 +1273,7 @@ __global__ void __launch_bounds__(WF_MAX_THREADS, LDS ? WF_WAVES_LDS : WF_WAVES_
             const int cnt[5] = {cBox, cPrim, cShade, cPath, cRef};
             const int slot = chosen == OP_REFBOX ? 6 : chosen;
             schedExec[slot] += 1;
-            schedLanes[slot] += cnt[chosen];
+            schedLanes[slot] += MERGE && chosen == OP_SHADE ? cShade + cPath : cnt[chosen];
         }
         lap(T_REST);
         if (chosen == OP_BOX || chosen == OP_PRIM) {
@@ -1453,7 +1470,10 @@ __global__ void __launch_bounds__(WF_MAX_THREADS, LDS ? WF_WAVES_LDS : WF_WAVES_
             } while (popc64(__ballot(op == OP_REFBOX)) >= keep && keep > 0);
             lap(T_REFBOX);
         }
-        if (chosen == OP_SHADE) {
+        bool fresh = false, againRef = false;  // MERGE: the lane has a new ray, to be set up at the end of the phase
+        (void)fresh;
+        (void)againRef;
+        if (chosen == OP_SHADE && (!MERGE || cShade > 0)) {
             // Flat on purpose (one level of conditions, outcomes chosen by selects): every level of a nest makes
             // the compiler copy the whole lane state.
             const bool shading = op == OP_SHADE;
@@ -1487,17 +1507,26 @@ __global__ void __launch_bounds__(WF_MAX_THREADS, LDS ? WF_WAVES_LDS : WF_WAVES_
                 }
                 r = out;
                 lap(T_SHADE_TAIL);
-                startRay();  // for a path that ends too: its lane state is dead, and NEWPATH overwrites it
-                lap(T_RAYSETUP);
-                if (ends) {
-                    if (COUNT) st.v[C_RAYS]--;
-                    depth = 0;
-                    op = OP_NEWPATH;
+                if (MERGE) {
+                    fresh = !ends;
+                    if (ends) {  // straight on to the next unit, below
+                        depth = 0;
+                        op = OP_NEWPATH;
+                    }
+                } else {
+                    startRay();  // for a path that ends too: its lane state is dead, and NEWPATH overwrites it
+                    lap(T_RAYSETUP);
+                    if (ends) {
+                        if (COUNT) st.v[C_RAYS]--;
+                        depth = 0;
+                        op = OP_NEWPATH;
+                    }
                 }
             }
             lap(T_SHADE_TAIL);
         }
-        if (chosen == OP_NEWPATH) {  // the next unit for every waiting lane, in lane order, and its camera ray
+        // the next unit for every waiting lane, in lane order, and its camera ray
+        if (MERGE ? (chosen == OP_SHADE && __ballot(op == OP_NEWPATH) != 0) : chosen == OP_NEWPATH) {
             const bool want = op == OP_NEWPATH;
             if (want && depth > 0) {  // the path this lane holds ended on the background
                 if (COUNT) st.v[C_MISS]++;
@@ -1577,12 +1606,17 @@ __global__ void __launch_bounds__(WF_MAX_THREADS, LDS ? WF_WAVES_LDS : WF_WAVES_
                     const int again = (int)(uw >> 31);  // the camera ray itself, to be traced in reference order
                     unit = uw & 0x7FFFFFFFu;
                     depth = a.max_depth - 1 + again;
-                    startRay();
-                    if (again) {
-                        idx = 0;
-                        op = OP_REFBOX;
-                        mode = 1;
-                        if (COUNT) st.v[C_RAYS]--;  // counted by the first pass
+                    if (MERGE) {
+                        fresh = true;
+                        againRef = again != 0;
+                    } else {
+                        startRay();
+                        if (again) {
+                            idx = 0;
+                            op = OP_REFBOX;
+                            mode = 1;
+                            if (COUNT) st.v[C_RAYS]--;  // counted by the first pass
+                        }
                     }
                 }
             } else {
@@ -1601,12 +1635,28 @@ __global__ void __launch_bounds__(WF_MAX_THREADS, LDS ? WF_WAVES_LDS : WF_WAVES_
                     if (COUNT) st.v[C_CUTOFF]++;
                     endPath(V3{0.0f, 0.0f, 0.0f});
                 } else {
-                    startRay();
+                    if (MERGE)
+                        fresh = true;
+                    else
+                        startRay();
                 }
             }
             }
             chunkNext += popc64(m);
             lap(T_CAMERA);
+        }
+        // one set-up of the new ray for the lanes that scattered and the lanes that took a new unit
+        if (MERGE && chosen == OP_SHADE) {
+            if (fresh) {
+                startRay();
+                if (SPLIT && againRef) {
+                    idx = 0;
+                    op = OP_REFBOX;
+                    mode = 1;
+                    if (COUNT) st.v[C_RAYS]--;  // counted by the first pass
+                }
+            }
+            lap(T_RAYSETUP);
         }
     }
     if (TIME && lane == 0) {
