@@ -1776,54 +1776,83 @@ __global__ void __launch_bounds__(WF_MAX_THREADS, WF_WAVES_LDS) primaryPass(Rend
             const float ex = epad * fabsf(invx), ey = epad * fabsf(invy), ez = epad * fabsf(invz);
             const f32x2 ax{nox - ex, nox + ex}, ay{noy - ey, noy + ey}, az{noz - ez, noz + ez};
             const uint32_t sx = (fbits(invx) >> 29) & 4u, sy = (fbits(invy) >> 29) & 4u, sz = (fbits(invz) >> 29) & 4u;
-            uint32_t e = walkBegin;  // wave-uniform
-            while (e < walkEnd) {
-                typedef __attribute__((address_space(3))) const float* LdsFloats;
-                typedef __attribute__((address_space(3))) const uint32_t* LdsWord;
-                const LdsBytes eb = (LdsBytes)(uintptr_t)e;
-                const LdsFloats qx = (LdsFloats)(eb + sx), qy = (LdsFloats)(eb + 12 + sy), qz = (LdsFloats)(eb + 24 + sz);
-                const f32x2u bx{qx[0], qx[1]}, by{qy[0], qy[1]}, bz{qz[0], qz[1]};
-                const uint32_t w = __builtin_amdgcn_readfirstlane(*(LdsWord)(eb + 36));
-                const f32x2 tx2 = __builtin_elementwise_fma(f32x2{bx.x, bx.y}, f32x2{invx, invx}, ax);
-                const f32x2 ty2 = __builtin_elementwise_fma(f32x2{by.x, by.y}, f32x2{invy, invy}, ay);
-                const f32x2 tz2 = __builtin_elementwise_fma(f32x2{bz.x, bz.y}, f32x2{invz, invz}, az);
-                const float tn = fmaxf(fmaxf(tx2.x, ty2.x), fmaxf(tz2.x, kTMin));
-                const float tf = fminf(fminf(tx2.y, ty2.y), fminf(tz2.y, h.t));
-                const bool pass = usable & (tn <= tf);
-                const unsigned long long any = __ballot(pass);
-                if (COUNT) {
-                    if (usable) st.v[C_NODE]++;
-                    stepExec += 1;
-                    stepLanes += popc64(__ballot(usable));
-                }
-                if (any == 0) {
-                    e = w & 0xFFFFu;
-                    continue;
-                }
-                e += kWalkEntryBytes;
-                const uint32_t first = w >> 16;
-                if (first >= kWalkEnd) continue;  // no leaf run under this entry
-                uint32_t p = first, ref;
-                do {
-                    ref = __builtin_amdgcn_readfirstlane(sv.frefs[p]);
-                    p += 1;
-                    if (pass) {
-                        float t, u = 0.0f, v = 0.0f;
-                        if (primRoot<COUNT, HAS>(sv, ref, r, aa, __builtin_inff(), t, u, v, &st)) {
-                            if (t != t) {
-                                bad = true;
-                            } else if (h.ref == kNoHit || t < h.t ||
-                                       (t == h.t && refOrder<HAS>(sv, ref) > refOrder<HAS>(sv, h.ref))) {
-                                h.t = t;
-                                h.ref = ref & ~kRefLast;
-                                if (HAS & S_TRIS) {
-                                    h.bu = u;
-                                    h.bv = v;
+            // The walk, compiled nine times: once for each sign pattern of the direction when all the wave's rays share
+            // it (nearly always: the rays of a tile are nearly parallel) -- the {entry, exit} plane pairs then sit at
+            // fixed offsets of the entry, and the four LDS reads of a step need no address arithmetic -- and once with
+            // the offsets per lane.
+            auto walk = [&](auto fixedSigns, auto signPattern) {
+                constexpr bool FIXED = decltype(fixedSigns)::value;
+                constexpr uint32_t KX = (decltype(signPattern)::value & 1) ? 4u : 0u, KY = (decltype(signPattern)::value & 2) ? 4u : 0u,
+                                   KZ = (decltype(signPattern)::value & 4) ? 4u : 0u;
+                uint32_t e = walkBegin;  // wave-uniform
+                while (e < walkEnd) {
+                    typedef __attribute__((address_space(3))) const float* LdsFloats;
+                    typedef __attribute__((address_space(3))) const uint32_t* LdsWord;
+                    const LdsBytes eb = (LdsBytes)(uintptr_t)e;
+                    const LdsFloats qx = (LdsFloats)(eb + (FIXED ? KX : sx)), qy = (LdsFloats)(eb + 12 + (FIXED ? KY : sy)),
+                                    qz = (LdsFloats)(eb + 24 + (FIXED ? KZ : sz));
+                    const f32x2u bx{qx[0], qx[1]}, by{qy[0], qy[1]}, bz{qz[0], qz[1]};
+                    const uint32_t w = __builtin_amdgcn_readfirstlane(*(LdsWord)(eb + 36));
+                    const f32x2 tx2 = __builtin_elementwise_fma(f32x2{bx.x, bx.y}, f32x2{invx, invx}, ax);
+                    const f32x2 ty2 = __builtin_elementwise_fma(f32x2{by.x, by.y}, f32x2{invy, invy}, ay);
+                    const f32x2 tz2 = __builtin_elementwise_fma(f32x2{bz.x, bz.y}, f32x2{invz, invz}, az);
+                    const float tn = fmaxf(fmaxf(tx2.x, ty2.x), fmaxf(tz2.x, kTMin));
+                    // min(tz2.y, h.t) on the bit patterns, as in the loop's box step (neither is a NaN, h.t is not negative)
+                    const int zi = __float_as_int(tz2.y), hi = __float_as_int(h.t);
+                    const float tf = fminf(fminf(tx2.y, ty2.y), __int_as_float(zi < hi ? zi : hi));
+                    const bool pass = usable & (tn <= tf);
+                    const unsigned long long any = __builtin_amdgcn_ballot_w64(pass);
+                    if (COUNT) {
+                        if (usable) st.v[C_NODE]++;
+                        stepExec += 1;
+                        stepLanes += popc64(__ballot(usable));
+                    }
+                    if (any == 0) {
+                        e = w & 0xFFFFu;
+                        continue;
+                    }
+                    e += kWalkEntryBytes;
+                    const uint32_t first = w >> 16;
+                    if (first >= kWalkEnd) continue;  // no leaf run under this entry
+                    uint32_t p = first, ref;
+                    do {
+                        ref = __builtin_amdgcn_readfirstlane(sv.frefs[p]);
+                        p += 1;
+                        if (pass) {
+                            float t, u = 0.0f, v = 0.0f;
+                            if (primRoot<COUNT, HAS>(sv, ref, r, aa, __builtin_inff(), t, u, v, &st)) {
+                                if (t != t) {
+                                    bad = true;
+                                } else if (h.ref == kNoHit || t < h.t ||
+                                           (t == h.t && refOrder<HAS>(sv, ref) > refOrder<HAS>(sv, h.ref))) {
+                                    h.t = t;
+                                    h.ref = ref & ~kRefLast;
+                                    if (HAS & S_TRIS) {
+                                        h.bu = u;
+                                        h.bv = v;
+                                    }
                                 }
                             }
                         }
-                    }
-                } while (!(ref & kRefLast));
+                    } while (!(ref & kRefLast));
+                }
+            };
+            const unsigned long long mU = __builtin_amdgcn_ballot_w64(usable);
+            const unsigned long long mX = __builtin_amdgcn_ballot_w64(usable && sx != 0), mY = __builtin_amdgcn_ballot_w64(usable && sy != 0),
+                                     mZ = __builtin_amdgcn_ballot_w64(usable && sz != 0);
+            if ((mX == 0 || mX == mU) && (mY == 0 || mY == mU) && (mZ == 0 || mZ == mU)) {
+                switch ((mX ? 1 : 0) | (mY ? 2 : 0) | (mZ ? 4 : 0)) {
+                    case 0: walk(std::true_type{}, std::integral_constant<int, 0>{}); break;
+                    case 1: walk(std::true_type{}, std::integral_constant<int, 1>{}); break;
+                    case 2: walk(std::true_type{}, std::integral_constant<int, 2>{}); break;
+                    case 3: walk(std::true_type{}, std::integral_constant<int, 3>{}); break;
+                    case 4: walk(std::true_type{}, std::integral_constant<int, 4>{}); break;
+                    case 5: walk(std::true_type{}, std::integral_constant<int, 5>{}); break;
+                    case 6: walk(std::true_type{}, std::integral_constant<int, 6>{}); break;
+                    default: walk(std::true_type{}, std::integral_constant<int, 7>{}); break;
+                }
+            } else {
+                walk(std::false_type{}, std::integral_constant<int, 0>{});
             }
         }
         // what becomes of the path: 0 = ended (colour written), 1 = goes on with the scattered ray, 2 = the camera
