@@ -1071,14 +1071,16 @@ __device__ __forceinline__ int popc64(unsigned long long m) {
 // SPLIT: second pass of a two-pass launch.  primaryPass() has traced and shaded every path's camera ray a whole
 // tile at a time and left one record per path that goes on; NEWPATH then hands a lane the next record instead of
 // a pixel sample, and the queue counts chunks of 64 records.
-template <bool LDS, bool COUNT, bool TIME = false, int HAS = S_ALL, bool NMAP = false, bool SPLIT = false>
+template <bool LDS, bool COUNT, bool TIME = false, int HAS = S_ALL, bool NMAP = false, bool SPLIT = false, bool ONEPHASE = false>
 __global__ void __launch_bounds__(WF_MAX_THREADS, LDS ? WF_WAVES_LDS : WF_WAVES_GLOBAL) renderWavefront(RenderArgs a) {
     const DevScene& sc = a.sc;
     // Second pass of a two-pass launch: SHADE and NEWPATH run as ONE phase.  Taking the next record is a handful of
     // loads there, both end with a new ray being set up, and a lane whose path ends in SHADE takes its next record in
     // the same turn of the loop (two-pass 20.1 -> 18.7 ms; with camera rays in NEWPATH the merged phase loses:
-    // single pass 20.0 -> 20.4 ms).
-    constexpr bool MERGE = SPLIT;
+    // single pass 20.0 -> 20.4 ms).  ONEPHASE asks for the same in a single-pass launch: it pays for small scenes in
+    // global memory, whose paths are long and whose time goes into shading (Cornell + vase 222 -> 211.5 ms), not for
+    // the large ones (1 M triangles 60.6 -> 62.5 ms).
+    constexpr bool MERGE = SPLIT || ONEPHASE;
     // a first pass that was cut short has not written all its records: nothing to go on with
     if (SPLIT && a.queue[1]) return;
     fillCounterLut<(HAS & S_PBR) != 0>(sc.lut);
@@ -2063,13 +2065,13 @@ __global__ void __launch_bounds__(256) resolveKernel(const float4* payloads, siz
 }
 
 // ------------------------------------------------------------------ launch wrappers
-template <bool LDS, bool COUNT, bool TIME = false, int HAS = S_ALL, bool NMAP = false>
+template <bool LDS, bool COUNT, bool TIME = false, int HAS = S_ALL, bool NMAP = false, bool ONEPHASE = false>
 static hipError_t launchWavefrontT(const RenderArgs& a, int blocks, int threads, size_t shmem, hipStream_t stream) {
     (void)hipGetLastError();  // an earlier, unrelated failure must not be reported as this launch's
     if (LDS)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(renderWavefront<LDS, COUNT, TIME, HAS, NMAP>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(renderWavefront<LDS, COUNT, TIME, HAS, NMAP, false, ONEPHASE>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    renderWavefront<LDS, COUNT, TIME, HAS, NMAP><<<blocks, threads, shmem, stream>>>(a);
+    renderWavefront<LDS, COUNT, TIME, HAS, NMAP, false, ONEPHASE><<<blocks, threads, shmem, stream>>>(a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const int nSlots = a.n_local_tiles * 64;
@@ -2106,6 +2108,17 @@ hipError_t launchWavefront(const RenderArgs& a, bool lds, bool count, int blocks
     if (count)
         return lds ? launchWavefrontT<true, true>(a, blocks, threads, shmem, stream)
                    : launchWavefrontT<false, true>(a, blocks, threads, 0, stream);
+    // small scenes read through the caches (one XCD's L2 holds the eight copies of their search structure) run
+    // SHADE and NEWPATH as one phase
+    const char* oneEnv = std::getenv("RT_ONE_PHASE");
+    const bool onePhase = !lds && (oneEnv ? std::atoi(oneEnv) != 0 : (size_t)a.sc.n_fast_nodes * 32 <= ((size_t)4 << 20));
+    if (onePhase) {
+        switch (sceneKind(a.sc)) {
+            case S_PLAIN: return launchWavefrontT<false, false, false, S_PLAIN, false, true>(a, blocks, threads, 0, stream);
+            case S_MESH: return launchWavefrontT<false, false, false, S_MESH, false, true>(a, blocks, threads, 0, stream);
+            default: return launchWavefrontT<false, false, false, S_ALL, false, true>(a, blocks, threads, 0, stream);
+        }
+    }
     switch (sceneKind(a.sc)) {
         case S_PLAIN:
             return lds ? launchWavefrontT<true, false, false, S_PLAIN>(a, blocks, threads, shmem, stream)
