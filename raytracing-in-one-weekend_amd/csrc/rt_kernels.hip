@@ -2113,10 +2113,15 @@ hipError_t launchWavefront(const RenderArgs& a, bool lds, bool count, int blocks
     const char* oneEnv = std::getenv("RT_ONE_PHASE");
     const bool onePhase = !lds && (oneEnv ? std::atoi(oneEnv) != 0 : (size_t)a.sc.n_fast_nodes * 32 <= ((size_t)4 << 20));
     if (onePhase) {
-        switch (sceneKind(a.sc)) {
-            case S_PLAIN: return launchWavefrontT<false, false, false, S_PLAIN, false, true>(a, blocks, threads, 0, stream);
-            case S_MESH: return launchWavefrontT<false, false, false, S_MESH, false, true>(a, blocks, threads, 0, stream);
-            default: return launchWavefrontT<false, false, false, S_ALL, false, true>(a, blocks, threads, 0, stream);
+        // this shape's best vote thresholds, unless the caller set its own (Cornell + vase: box bursts kept up for 16
+        // lanes and the joint phase started at 40 waiting lanes 207.7 ms, at the loop's general 8 / 32 211.6)
+        RenderArgs b = a;
+        if (!std::getenv("RT_BOX_KEEP")) b.knob[0] = 16;
+        if (!std::getenv("RT_SHADE_MIN")) b.knob[1] = 40;
+        switch (sceneKind(b.sc)) {
+            case S_PLAIN: return launchWavefrontT<false, false, false, S_PLAIN, false, true>(b, blocks, threads, 0, stream);
+            case S_MESH: return launchWavefrontT<false, false, false, S_MESH, false, true>(b, blocks, threads, 0, stream);
+            default: return launchWavefrontT<false, false, false, S_ALL, false, true>(b, blocks, threads, 0, stream);
         }
     }
     switch (sceneKind(a.sc)) {
