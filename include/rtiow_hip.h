@@ -153,7 +153,8 @@ int rt_scene_end_group(rt_scene* s);
  * numbers in both spaces --, the prototype's own Hit(), and the normal brought back through
  * mat3(transpose(inverse(model))) and normalised; the hit point is taken from the world ray.
  * One level only (no instance inside a prototype).  Scenes with instances are rendered along the reference-order
- * entries by the plain kernel (no search structure, no persistent loop), and not together with normal mapping.
+ * entries (they have no search structure) by a build of the persistent loop that walks the two levels, and not
+ * together with normal mapping.
  * model16: column-major.  Returns the instance's number. */
 int rt_scene_begin_prototype(rt_scene* s);
 int rt_scene_end_prototype(rt_scene* s);

@@ -101,7 +101,7 @@ def c5s(n_tris, w=1920, h=1080, spp=16, check=True):
 
 def c5i(n_tris, w=1920, h=1080, spp=16, check=True):
     """The large-mesh scene with true instances (rt_scene_add_instance): ONE vase held in its own space, placed
-    n_tris / 2,760 times.  Rendered by the plain kernel along the reference-order entries."""
+    n_tris / 2,760 times.  Rendered along the reference-order entries (two levels)."""
     mesh = scenes.load_gltf_mesh(G)
     per = mesh["indices"].shape[0]
     copies = max(1, n_tris // per)

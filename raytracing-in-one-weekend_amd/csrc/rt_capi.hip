@@ -197,8 +197,7 @@ int launch(rt_context* ctx, rt::RenderArgs& a, bool count, const Workspace* fixe
     const int threads = 256;
     const int wavesPerBlock = threads / 64;
     const char* kernel = std::getenv("RT_KERNEL");
-    // scenes with instances are rendered by the plain kernel (it walks the two levels; the persistent loop does not)
-    const bool simple = (kernel && std::strcmp(kernel, "simple") == 0 && !fixed) || a.sc.n_instances > 0;
+    const bool simple = kernel && std::strcmp(kernel, "simple") == 0 && !fixed;
     int blocks;
     if (simple) {
         blocks = (a.n_local_tiles + wavesPerBlock - 1) / wavesPerBlock;

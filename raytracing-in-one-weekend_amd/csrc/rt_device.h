@@ -33,8 +33,8 @@ struct DevScene {
     // Instancing (opt-in): entries [0, n_world_nodes) of `nodes` are the world's, the prototypes' entries follow;
     // an instance is a world entry with bit 29 of its skip word set and the instance's number in its first_ref
     // word.  Five float4 per instance: the inverse model matrix column by column, then {first entry, end entry
-    // of its prototype (ints bit-cast), -, -}.  Scenes with instances are rendered by the plain kernel along the
-    // reference-order entries only.
+    // of its prototype (ints bit-cast), -, -}.  Scenes with instances are rendered along the reference-order entries
+    // only (renderWavefront<INST>; the plain kernel and the trace hook walk the two levels too).
     const float4* instances;
     int n_instances, n_world_nodes;
     int fast_oct_stride;      // > 0: fast_nodes holds 8 direction-ordered copies of this many entries each

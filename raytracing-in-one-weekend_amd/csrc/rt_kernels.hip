@@ -68,6 +68,10 @@ __shared__ int g_cancelSeen;  // set by the workgroup's first wave once it has r
 // followed by three look-ups, which then cost an LDS read each instead of a trip to L1 / L2
 __shared__ float g_texLut[256];
 
+// Instancing in the persistent loop: a lane's world-space ray (origin, direction) while the lane walks a prototype
+// in object space, one slot per thread (only the build for scenes with instances refers to it)
+__shared__ float g_worldRay[6][WF_MAX_THREADS];
+
 template <bool TEX = false>
 __device__ __forceinline__ void fillCounterLut(const float* texLut = nullptr) {
     for (int i = threadIdx.x; i < kCounterLut; i += blockDim.x) g_counterLut[i] = hashu(fbits((float)i));
@@ -415,7 +419,7 @@ __device__ __forceinline__ Hit traverseRef(const SceneView& sv, int n_nodes, con
     return h;
 }
 
-// ------------------------------------------------------------------ instancing (opt-in; plain kernel only)
+// ------------------------------------------------------------------ instancing (opt-in): plain kernel and trace hook
 // The reference has no instances: it bakes every placement into world-space triangles
 // (R/src/Core/Mesh.cpp:106-208).  What an instance means here is defined by the CPU oracle's Instance class,
 // which these functions follow expression by expression.
@@ -1065,14 +1069,18 @@ __device__ __forceinline__ int popc64(unsigned long long m) {
 #ifndef WF_WAVES_GLOBAL
 #define WF_WAVES_GLOBAL 8
 #endif
+#ifndef WF_WAVES_INST
+#define WF_WAVES_INST 8
+#endif
 // TIME (diagnostic): instead of path counters, each wave adds up its clock ticks per operation
 // -- box bursts, primitive runs, SHADE, NEWPATH, reference-order box steps, and everything else
 // (votes, loop overhead) -- into the scheduling-statistics slots.
 // SPLIT: second pass of a two-pass launch.  primaryPass() has traced and shaded every path's camera ray a whole
 // tile at a time and left one record per path that goes on; NEWPATH then hands a lane the next record instead of
 // a pixel sample, and the queue counts chunks of 64 records.
-template <bool LDS, bool COUNT, bool TIME = false, int HAS = S_ALL, bool NMAP = false, bool SPLIT = false, bool ONEPHASE = false>
-__global__ void __launch_bounds__(WF_MAX_THREADS, LDS ? WF_WAVES_LDS : WF_WAVES_GLOBAL) renderWavefront(RenderArgs a) {
+template <bool LDS, bool COUNT, bool TIME = false, int HAS = S_ALL, bool NMAP = false, bool SPLIT = false, bool ONEPHASE = false,
+          bool INST = false>
+__global__ void __launch_bounds__(WF_MAX_THREADS, LDS ? WF_WAVES_LDS : (INST ? WF_WAVES_INST : WF_WAVES_GLOBAL)) renderWavefront(RenderArgs a) {
     const DevScene& sc = a.sc;
     // Second pass of a two-pass launch: SHADE and NEWPATH run as ONE phase.  Taking the next record is a handful of
     // loads there, both end with a new ray being set up, and a lane whose path ends in SHADE takes its next record in
@@ -1093,7 +1101,7 @@ __global__ void __launch_bounds__(WF_MAX_THREADS, LDS ? WF_WAVES_LDS : WF_WAVES_
     const int lane = threadIdx.x & 63;
     // `idx` of a lane that walks the search structure: the entry's number, or with the tables in LDS the
     // LDS address of its walk entry; walkEnd is the value that means "past the last entry"
-    const int nNodesRef = sc.n_nodes, nNodesFast = sc.n_fast_nodes;
+    const int nNodesRef = INST ? sc.n_world_nodes : sc.n_nodes, nNodesFast = sc.n_fast_nodes;
     const int walkBegin = LDS ? (int)ldsAddress(sv.wnodes) : 0;
     const int walkEnd = LDS ? walkBegin + nNodesFast * kWalkEntryBytes : nNodesFast;
     const float originLimit = sc.origin_limit;
@@ -1123,6 +1131,11 @@ __global__ void __launch_bounds__(WF_MAX_THREADS, LDS ? WF_WAVES_LDS : WF_WAVES_
     // 0: the lane walks the search structure; 1: it walks the reference-order array (diagnostic
     // setting, zero direction component, or a re-trace after a failed guard test / NaN distance)
     int mode = 0;
+    // INST (scenes with instances; they walk the reference-order entries only): while the lane is inside a prototype's
+    // entries -- with its ray in object space, the world ray parked in g_worldRay -- `back` is the world entry to go
+    // on with afterwards (-1: not inside one) and rangeEnd the end of the prototype's entries (else of the world's);
+    // inInst / hitInst: the placement being walked, and the one the closest hit so far was found through (-1: none)
+    int back = -1, rangeEnd = nNodesRef, inInst = -1, hitInst = -1;
 
     // The wave's current chunk of the queue: 64 units = the 64 pixels of one tile for one sample.
     // chunkNext counts the lanes' worth already handed out (64 = used up), chunk < 0 = queue dry.
@@ -1215,10 +1228,33 @@ __global__ void __launch_bounds__(WF_MAX_THREADS, LDS ? WF_WAVES_LDS : WF_WAVES_
         // the boxes it tests; with the tables in global memory it walks the reference-order array instead
         // tables in LDS: the widening itself, branch-free; tables in global memory: only whether there is one
         if (LDS) epad = farRayPad(sc, r.o);
-        mode = (sc.force_ref || (!LDS && startsFar(sc, r.o)) || !fastTestUsable(r.o, originLimit, invx, invy, invz, nox, noy, noz)) ? 1 : 0;
+        mode = (INST || sc.force_ref || (!LDS && startsFar(sc, r.o)) || !fastTestUsable(r.o, originLimit, invx, invy, invz, nox, noy, noz)) ? 1 : 0;
         op = mode ? OP_REFBOX : OP_BOX;
         if (mode) idx = 0;  // the reference-order array has one order only
+        if (INST) {
+            back = -1;
+            rangeEnd = nNodesRef;
+            hitInst = -1;
+        }
         if (COUNT) st.v[C_RAYS]++;
+    };
+    // INST: the end of a range of reference-order entries -- of a prototype's (back to the world's entries, with the
+    // world ray) or of the world's (the walk is over)
+    auto endOfRange = [&]() {
+        if (INST && back >= 0) {
+            r.o = V3{g_worldRay[0][threadIdx.x], g_worldRay[1][threadIdx.x], g_worldRay[2][threadIdx.x]};
+            r.d = V3{g_worldRay[3][threadIdx.x], g_worldRay[4][threadIdx.x], g_worldRay[5][threadIdx.x]};
+            invx = 1.0f / r.d.x;
+            invy = 1.0f / r.d.y;
+            invz = 1.0f / r.d.z;
+            if (carriesAa) aa = dot(r.d, r.d);
+            idx = back;
+            back = -1;
+            rangeEnd = nNodesRef;
+            op = idx >= nNodesRef ? (h.ref == kNoHit ? OP_NEWPATH : OP_SHADE) : OP_REFBOX;
+        } else {
+            op = h.ref == kNoHit ? OP_NEWPATH : OP_SHADE;
+        }
     };
     auto retraceInReferenceOrder = [&]() {
         h.t = __builtin_inff();
@@ -1240,7 +1276,7 @@ __global__ void __launch_bounds__(WF_MAX_THREADS, LDS ? WF_WAVES_LDS : WF_WAVES_
     auto afterWalk = [&]() { return h.ref == kNoHit ? OP_NEWPATH : OP_SHADE; };
 
     for (;;) {
-        const int cBox = popc64(__ballot(op == OP_BOX)), cPrim = popc64(__ballot(op == OP_PRIM)),
+        const int cBox = INST ? 0 : popc64(__ballot(op == OP_BOX)), cPrim = popc64(__ballot(op == OP_PRIM)),
                   cShade = popc64(__ballot(op == OP_SHADE)), cPath = popc64(__ballot(op == OP_NEWPATH)),
                   cRef = popc64(__ballot(op == OP_REFBOX));
         if ((cBox | cPrim | cShade | cPath | cRef) == 0) break;
@@ -1285,7 +1321,7 @@ __global__ void __launch_bounds__(WF_MAX_THREADS, LDS ? WF_WAVES_LDS : WF_WAVES_
             const int total = cBox + cPrim + cShade + cPath + cRef;  // lanes that are not done
             int nBox = cBox, cur = chosen;
             for (;;) {
-                if (cur == OP_BOX && LDS) {
+                if (cur == OP_BOX && LDS && !INST) {
                     // Search structure in LDS: conservative fused box test on walk entries.  For the length
                     // of the burst a lane's membership is the flag `walking` (a lane mask in scalar registers)
                     // rather than `op`, the entry/exit planes come sorted from the entry's layout, and the end
@@ -1345,7 +1381,7 @@ __global__ void __launch_bounds__(WF_MAX_THREADS, LDS ? WF_WAVES_LDS : WF_WAVES_
                         op = first == kWalkEnd ? afterWalk() : OP_PRIM;
                     }
                     lap(T_BOX);
-                } else if (cur == OP_BOX) {
+                } else if (cur == OP_BOX && !INST) {
                     // Search structure: conservative fused box test.  An entry that passes and carries
                     // a leaf run sends the lane to PRIM; `idx` already names the entry to go on with.
                     const int keep = boxKeep < nBox ? boxKeep : nBox;  // never spin below what is available
@@ -1410,12 +1446,20 @@ __global__ void __launch_bounds__(WF_MAX_THREADS, LDS ? WF_WAVES_LDS : WF_WAVES_
                                         h.bu = u;
                                         h.bv = v;
                                     }
+                                    if (INST) hitInst = back >= 0 ? inInst : -1;
                                 }
                             }
                             if (bad) {
                                 retraceInReferenceOrder();
                             } else if (ref & kRefLast) {
-                                op = idx >= (mode ? nNodesRef : walkEnd) ? afterWalk() : (mode ? OP_REFBOX : OP_BOX);
+                                if (INST) {
+                                    if (idx >= rangeEnd)
+                                        endOfRange();
+                                    else
+                                        op = OP_REFBOX;
+                                } else {
+                                    op = idx >= (mode ? nNodesRef : walkEnd) ? afterWalk() : (mode ? OP_REFBOX : OP_BOX);
+                                }
                             } else {
                                 p += 1;
                             }
@@ -1433,7 +1477,7 @@ __global__ void __launch_bounds__(WF_MAX_THREADS, LDS ? WF_WAVES_LDS : WF_WAVES_
                     }
                     lap(T_PRIM);
                 }
-                nBox = popc64(__ballot(op == OP_BOX));
+                nBox = INST ? 0 : popc64(__ballot(op == OP_BOX));
                 const int nPrim = popc64(__ballot(op == OP_PRIM));
                 const int others = total - nBox - nPrim;
                 const int best = nBox > nPrim ? nBox : nPrim;
@@ -1461,12 +1505,42 @@ __global__ void __launch_bounds__(WF_MAX_THREADS, LDS ? WF_WAVES_LDS : WF_WAVES_
                     const bool nobox = (w3 & kNoBox) != 0;
                     if (COUNT && !nobox) st.v[C_NODE]++;
                     const bool pass = slabPass(n0, n1, r, invx, invy, invz, h.t) || nobox;
-                    idx = pass ? idx + 1 : (int)(w3 & kSkipMask);
-                    if (pass && first >= 0) {
-                        p = first;
-                        op = OP_PRIM;
-                    } else if (idx >= nNodesRef) {
-                        op = afterWalk();
+                    if (INST && (w3 & kNodeInstance)) {
+                        // a placement (the oracle's Instance::Hit): its box passed -> the prototype's entries with the ray
+                        // in object space, the world ray parked; else on to the next world entry
+                        if (pass) {
+                            g_worldRay[0][threadIdx.x] = r.o.x;
+                            g_worldRay[1][threadIdx.x] = r.o.y;
+                            g_worldRay[2][threadIdx.x] = r.o.z;
+                            g_worldRay[3][threadIdx.x] = r.d.x;
+                            g_worldRay[4][threadIdx.x] = r.d.y;
+                            g_worldRay[5][threadIdx.x] = r.d.z;
+                            const float4* I = sc.instances + 5 * first;
+                            const float4 range = I[4];
+                            r = toObjectSpace(I, r);
+                            invx = 1.0f / r.d.x;
+                            invy = 1.0f / r.d.y;
+                            invz = 1.0f / r.d.z;
+                            if (carriesAa) aa = dot(r.d, r.d);
+                            back = idx + 1;
+                            inInst = first;
+                            idx = (int)fbits(range.x);
+                            rangeEnd = (int)fbits(range.y);
+                        } else {
+                            idx = idx + 1;
+                            if (idx >= rangeEnd) endOfRange();
+                        }
+                    } else {
+                        idx = pass ? idx + 1 : (int)(w3 & kSkipMask);
+                        if (pass && first >= 0) {
+                            p = first;
+                            op = OP_PRIM;
+                        } else if (idx >= (INST ? rangeEnd : nNodesRef)) {
+                            if (INST)
+                                endOfRange();
+                            else
+                                op = afterWalk();
+                        }
                     }
                 }
             } while (popc64(__ballot(op == OP_REFBOX)) >= keep && keep > 0);
@@ -1484,7 +1558,7 @@ __global__ void __launch_bounds__(WF_MAX_THREADS, LDS ? WF_WAVES_LDS : WF_WAVES_
             lap(T_GUARD);
             if (shading & !vouched) retraceInReferenceOrder();
             if (shading & vouched) {
-                Surface sf = surfaceAt<HAS>(sc, sv, r, h);
+                Surface sf = INST ? surfaceAtInstanced(sc, sv, r, h, hitInst) : surfaceAt<HAS>(sc, sv, r, h);
                 lap(T_SURFACE);
                 const float4 m0 = sv.materials[2 * sf.mat], m1 = sv.materials[2 * sf.mat + 1];
                 V3 ball{0.0f, 0.0f, 0.0f};
@@ -2065,13 +2139,13 @@ __global__ void __launch_bounds__(256) resolveKernel(const float4* payloads, siz
 }
 
 // ------------------------------------------------------------------ launch wrappers
-template <bool LDS, bool COUNT, bool TIME = false, int HAS = S_ALL, bool NMAP = false, bool ONEPHASE = false>
+template <bool LDS, bool COUNT, bool TIME = false, int HAS = S_ALL, bool NMAP = false, bool ONEPHASE = false, bool INST = false>
 static hipError_t launchWavefrontT(const RenderArgs& a, int blocks, int threads, size_t shmem, hipStream_t stream) {
     (void)hipGetLastError();  // an earlier, unrelated failure must not be reported as this launch's
     if (LDS)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(renderWavefront<LDS, COUNT, TIME, HAS, NMAP, false, ONEPHASE>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(renderWavefront<LDS, COUNT, TIME, HAS, NMAP, false, ONEPHASE, INST>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    renderWavefront<LDS, COUNT, TIME, HAS, NMAP, false, ONEPHASE><<<blocks, threads, shmem, stream>>>(a);
+    renderWavefront<LDS, COUNT, TIME, HAS, NMAP, false, ONEPHASE, INST><<<blocks, threads, shmem, stream>>>(a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const int nSlots = a.n_local_tiles * 64;
@@ -2094,6 +2168,10 @@ static int sceneKind(const DevScene& sc) {
 hipError_t launchWavefront(const RenderArgs& a, bool lds, bool count, int blocks, int threads, hipStream_t stream) {
     (void)hipGetLastError();  // an earlier, unrelated failure must not be reported as this launch's
     size_t shmem = lds ? (size_t)a.lds_bytes : 0;
+    // scenes with instances: the build of the loop that walks the two levels (reference-order entries, global memory)
+    if (a.sc.n_instances > 0)
+        return count ? launchWavefrontT<false, true, false, S_ALL, false, false, true>(a, blocks, threads, 0, stream)
+                     : launchWavefrontT<false, false, false, S_ALL, false, false, true>(a, blocks, threads, 0, stream);
     if (count && a.timing)
         return lds ? launchWavefrontT<true, false, true>(a, blocks, threads, shmem, stream)
                    : launchWavefrontT<false, false, true>(a, blocks, threads, 0, stream);
