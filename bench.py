@@ -292,7 +292,10 @@ def main():
             "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_FP32_TFLOPS, 4),
             "traffic": prof.get("hbm_bytes_per_launch"),   # null when the PMC passes predate the kernel sources
-            "kernel": "rt::renderWavefront<true, false, false, false, false, false> (tables in LDS, spheres-only build)",
+            # the launch as a whole: first pass (camera rays, a tile at a time), the persistent loop over its path
+            # records (about three quarters of the time), and the ordered per-pixel sums
+            "kernel": "rt::primaryPass<false, 9, false> + rt::renderWavefront<true, false, false, 9, false, true, false, false> "
+                      "+ rt::accumulateColors (tables in LDS, spheres-only builds)",
             "kernel_ms": round(avg_kernel_ms, 4),
             "flops_per_sample": round(flops_per_sample, 1),
             "rays_per_sample": round(counters["rays"] / counters["samples"], 3),

@@ -19,7 +19,7 @@ def main(root):
                 "select kernel_name, counter_name, count(distinct dispatch_id), sum(value), "
                 "sum(value) / count(distinct dispatch_id), max(vgpr_count), max(sgpr_count), "
                 "max(lds_block_size), max(workgroup_size), max(grid_size) from counters_collection "
-                "where kernel_name like '%render%' group by kernel_name, counter_name"))
+                "where (kernel_name like '%render%' or kernel_name like '%primaryPass%') group by kernel_name, counter_name"))
         except sqlite3.Error as e:
             rows = []
             print("pmc query failed:", e)

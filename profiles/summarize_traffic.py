@@ -3,7 +3,7 @@
 rocprofv3 reports both counters in kilobytes.  On gfx950 FETCH_SIZE tallies the 128-byte read
 requests of wide coalesced loads (16 B per lane: the colour-buffer and accumulation-buffer reads
 here) at 64 bytes, so it is doubled; WRITE_SIZE is exact for 16-B-per-lane stores.
-bytes = (2 * fetch + write) * 1024, render kernel + ordered-sum kernel of one launch.
+bytes = (2 * fetch + write) * 1024, the kernels of one launch: first pass, loop, ordered sum.
 Usage: python profiles/summarize_traffic.py gpurun_out/prof_<tag>"""
 import glob
 import json
@@ -17,12 +17,11 @@ from bench import kernel_source_hash  # noqa: E402
 
 
 def per_dispatch(root, counter):
-    """Average per dispatch of the render kernel plus average per dispatch of the ordered-sum kernel
-    that follows every render launch."""
+    """Average per dispatch of each kernel of a render launch (first pass, loop, ordered sum), added up."""
     for db_path in sorted(glob.glob(os.path.join(root, "*", "*_results.db"))):
         cur = sqlite3.connect(db_path).cursor()
         total, found = 0.0, False
-        for pattern in ("%renderWavefront<true, false, false,%", "%accumulateColors%"):
+        for pattern in ("%primaryPass<false,%", "%renderWavefront<true, false, false,%", "%accumulateColors%"):
             try:
                 rows = list(cur.execute(
                     "select sum(value) / count(distinct dispatch_id) from counters_collection "
@@ -38,17 +37,22 @@ def per_dispatch(root, counter):
 
 
 def render_kernel(root, counter):
-    """Average per dispatch of the render kernel alone."""
+    """Average per dispatch of the two render kernels of a launch (first pass + loop), added up."""
     for db_path in sorted(glob.glob(os.path.join(root, "*", "*_results.db"))):
         cur = sqlite3.connect(db_path).cursor()
-        try:
-            rows = list(cur.execute(
-                "select sum(value) / count(distinct dispatch_id) from counters_collection "
-                "where counter_name = ? and kernel_name like ?", (counter, "%renderWavefront<true, false, false,%")))
-        except sqlite3.Error:
-            rows = []
-        if rows and rows[0][0] is not None:
-            return float(rows[0][0])
+        total, found = 0.0, False
+        for pattern in ("%primaryPass<false,%", "%renderWavefront<true, false, false,%"):
+            try:
+                rows = list(cur.execute(
+                    "select sum(value) / count(distinct dispatch_id) from counters_collection "
+                    "where counter_name = ? and kernel_name like ?", (counter, pattern)))
+            except sqlite3.Error:
+                rows = []
+            if rows and rows[0][0] is not None:
+                total += float(rows[0][0])
+                found = True
+        if found:
+            return total
     return None
 
 
