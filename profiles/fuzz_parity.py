@@ -1,5 +1,6 @@
 """Randomised parity run: many small random worlds (spheres of all four materials, loose triangles,
-lathe meshes with smooth or flat normals and PBR (a third of them normal-mapped) or Lambertian materials, lights), random cameras
+lathe meshes with smooth or flat normals and PBR (a third of them normal-mapped) or Lambertian materials -- baked, or in
+every fourth world held once and placed by transforms --, lights), random cameras
 (inside and outside the world, with and without a lens), with and without the reference's top-level
 BVH; every accumulation image of the GPU path must equal the CPU oracle's bit for bit.
 
@@ -49,6 +50,25 @@ def make_builder(seed):
         model = scenes.translate_scale(tuple((rr.rand(3) * extent * 0.5).astype(np.float32)),
                                        (extent * float(0.5 + rr.rand()),) * 3)
         meshes.append((m, model, int(rr.choice([-1, 0, 1, 3])), rr.rand() < 0.5, rr.rand() < 0.5, rr.rand() < 0.5))
+    # every fourth world places its meshes as instances (held once in their own space, 1-4 placements each by a
+    # rotation, an uneven scale and a shift) instead of baking them
+    placed = seed % 4 == 2 and n_mesh > 0
+    placements = []
+    if placed:
+        r2 = np.random.RandomState(seed + 991)
+        for _ in range(n_mesh):
+            ms = []
+            for _ in range(int(r2.randint(1, 5))):
+                axis = r2.randn(3)
+                axis /= np.linalg.norm(axis)
+                ang = float(r2.rand() * 2 * np.pi)
+                K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+                R = np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * (K @ K)
+                M = np.eye(4)
+                M[:3, :3] = R @ np.diag(0.5 + r2.rand(3))
+                M[:3, 3] = (r2.rand(3) - 0.25) * extent * 0.5
+                ms.append(M.astype(np.float32).T.reshape(16).copy())  # column-major
+            placements.append(ms)
     mat_draws = rr.rand(64, 5)
     wrap = rr.rand() < 0.6
     inside = rr.rand() < 0.5
@@ -65,7 +85,8 @@ def make_builder(seed):
     vfov = float(rr.choice([20.0, 40.0, 90.0]))
     bg = tuple(float(x) for x in rr.choice([0.0, 0.7, 1.0], 3))
     tex_seed = int(rr.randint(1 << 20))
-    normal_maps = seed % 3 == 0   # PBR meshes carry a normal map, and the scene's switch is on
+    # PBR meshes carry a normal map, and the scene's switch is on (not with placements: the library refuses that)
+    normal_maps = seed % 3 == 0 and not placed
 
     def build(s):
         mats = []
@@ -88,8 +109,14 @@ def make_builder(seed):
                 mat = s.add_pbr(td, tr, tn)
             else:
                 mat = mats[k % len(mats)]
+            if placed:
+                proto = s.begin_prototype()
             s.add_mesh(model, m["positions"], m["indices"], mat, normals=m["normals"] if smooth else None,
                        uvs=m["uvs"] if pbr else None, max_depth=depth)
+            if placed:
+                s.end_prototype()
+                for M in placements[k]:
+                    s.add_instance(proto, M)
         if wrap:
             s.wrap_bvh()
         s.set_camera(lookfrom, lookat, (0.0, 1.0, 0.0), vfov, 1.0, aperture, float(max(1e-3, np.linalg.norm(lookat - lookfrom))))

@@ -71,6 +71,13 @@ __shared__ float g_texLut[256];
 // Instancing in the persistent loop: a lane's world-space ray (origin, direction) while the lane walks a prototype
 // in object space, one slot per thread (only the build for scenes with instances refers to it)
 __shared__ float g_worldRay[6][WF_MAX_THREADS];
+// Scenes in global memory: the part of a lane's state that only SHADE and NEWPATH touch -- throughput, unit, depth
+// left -- lives here, read and written where it is used, instead of in registers carried through the walk and
+// through the scatter code.
+__shared__ float g_parked[5][WF_MAX_THREADS];
+#ifndef RT_PARK
+#define RT_PARK 1
+#endif
 
 template <bool TEX = false>
 __device__ __forceinline__ void fillCounterLut(const float* texLut = nullptr) {
@@ -1117,9 +1124,36 @@ __global__ void __launch_bounds__(WF_MAX_THREADS, LDS ? WF_WAVES_LDS : (INST ? W
         for (int i = 0; i < kNumStats; i++) st.v[i] = 0;
 
     int op = OP_NEWPATH;
-    int depth = 0, idx = 0, p = 0;
-    unsigned int unit = 0;
-    V3 thr{1.f, 1.f, 1.f};
+    int idx = 0, p = 0;
+    constexpr bool PARK = RT_PARK && !LDS && !INST && !COUNT && !TIME;
+    int depthKept = 0;
+    unsigned int unitKept = 0;
+    V3 thrKept{1.f, 1.f, 1.f};
+    auto getThr = [&]() { return PARK ? V3{g_parked[0][threadIdx.x], g_parked[1][threadIdx.x], g_parked[2][threadIdx.x]} : thrKept; };
+    auto setThr = [&](V3 v) {
+        if (PARK) {
+            g_parked[0][threadIdx.x] = v.x;
+            g_parked[1][threadIdx.x] = v.y;
+            g_parked[2][threadIdx.x] = v.z;
+        } else {
+            thrKept = v;
+        }
+    };
+    auto getUnit = [&]() { return PARK ? fbits(g_parked[3][threadIdx.x]) : unitKept; };
+    auto setUnit = [&](unsigned int u) {
+        if (PARK)
+            g_parked[3][threadIdx.x] = __uint_as_float(u);
+        else
+            unitKept = u;
+    };
+    auto getDepth = [&]() { return PARK ? (int)fbits(g_parked[4][threadIdx.x]) : depthKept; };
+    auto setDepth = [&](int d) {
+        if (PARK)
+            g_parked[4][threadIdx.x] = __uint_as_float((uint32_t)d);
+        else
+            depthKept = d;
+    };
+    setDepth(0);
     Rng rng{0u, 0u};
     Ray r{{0.f, 0.f, 0.f}, {0.f, 0.f, 1.f}};
     float invx = 0.f, invy = 0.f, invz = 0.f;
@@ -1265,9 +1299,9 @@ __global__ void __launch_bounds__(WF_MAX_THREADS, LDS ? WF_WAVES_LDS : (INST ? W
         if (COUNT) st.v[C_FALLBACK]++;
     };
     auto endPath = [&](V3 terminal) {
-        const V3 c = thr * terminal;
-        a.colors[unit] = Radiance{c.x, c.y, c.z};
-        depth = 0;  // nothing left to finish (see afterWalk)
+        const V3 c = getThr() * terminal;
+        a.colors[getUnit()] = Radiance{c.x, c.y, c.z};
+        setDepth(0);  // nothing left to finish (see afterWalk)
         op = OP_NEWPATH;
     };
     // Where a lane goes when its walk is over.  A ray that hit nothing needs no shading: the lane
@@ -1571,6 +1605,8 @@ __global__ void __launch_bounds__(WF_MAX_THREADS, LDS ? WF_WAVES_LDS : (INST ? W
                 // The path goes on with throughput x attenuation and the scattered ray, unless it was absorbed
                 // (terminal radiance `emit`) or has used up its depth (terminal radiance 0 = `emit` of a
                 // scattering material, times the attenuated throughput as the reference forms it).
+                V3 thr = getThr();
+                int depth = getDepth();
                 if (alive) {
                     thr = thr * atten;
                     depth -= 1;
@@ -1579,7 +1615,7 @@ __global__ void __launch_bounds__(WF_MAX_THREADS, LDS ? WF_WAVES_LDS : (INST ? W
                 if (COUNT && alive && depth <= 0) st.v[C_CUTOFF]++;
                 if (ends) {
                     const V3 c = thr * emit;
-                    a.colors[unit] = Radiance{c.x, c.y, c.z};
+                    a.colors[getUnit()] = Radiance{c.x, c.y, c.z};
                 }
                 r = out;
                 lap(T_SHADE_TAIL);
@@ -1598,13 +1634,15 @@ __global__ void __launch_bounds__(WF_MAX_THREADS, LDS ? WF_WAVES_LDS : (INST ? W
                         op = OP_NEWPATH;
                     }
                 }
+                setThr(thr);
+                setDepth(depth);
             }
             lap(T_SHADE_TAIL);
         }
         // the next unit for every waiting lane, in lane order, and its camera ray
         if (MERGE ? (chosen == OP_SHADE && __ballot(op == OP_NEWPATH) != 0) : chosen == OP_NEWPATH) {
             const bool want = op == OP_NEWPATH;
-            if (want && depth > 0) {  // the path this lane holds ended on the background
+            if (want && getDepth() > 0) {  // the path this lane holds ended on the background
                 if (COUNT) st.v[C_MISS]++;
                 endPath(V3{sc.bg[0], sc.bg[1], sc.bg[2]});
             }
@@ -1675,13 +1713,13 @@ __global__ void __launch_bounds__(WF_MAX_THREADS, LDS ? WF_WAVES_LDS : (INST ? W
                                  q2 = a.records[2 * (size_t)a.records_cap + rec];
                     r.o = V3{q0.x, q0.y, q0.z};
                     r.d = V3{q0.w, q1.x, q1.y};
-                    thr = V3{q1.z, q1.w, q2.x};
+                    setThr(V3{q1.z, q1.w, q2.x});
                     rng.key = fbits(q2.y);
                     rng.counter = fbits(q2.z);
                     const uint32_t uw = fbits(q2.w);
                     const int again = (int)(uw >> 31);  // the camera ray itself, to be traced in reference order
-                    unit = uw & 0x7FFFFFFFu;
-                    depth = a.max_depth - 1 + again;
+                    setUnit(uw & 0x7FFFFFFFu);
+                    setDepth(a.max_depth - 1 + again);
                     if (MERGE) {
                         fresh = true;
                         againRef = again != 0;
@@ -1698,16 +1736,16 @@ __global__ void __launch_bounds__(WF_MAX_THREADS, LDS ? WF_WAVES_LDS : (INST ? W
             } else {
             const int px = chunkX0 + (l & 7), py = chunkY0 + (l >> 3);
             if (want & (chunk >= 0) & (l < 64) & chunkInside & (px < a.width) & (py < a.height)) {
-                unit = (unsigned int)chunk * 64u + (unsigned int)l;
+                setUnit((unsigned int)chunk * 64u + (unsigned int)l);
                 rng.init((uint32_t)px, (uint32_t)py, chunkSample);
                 if (COUNT) st.v[C_SAMPLES]++;
                 // u is drawn before v (R/src/Core/Raytracer.cpp:86-87)
                 float u = ((float)px + rng.next()) / (float)(a.width - 1);
                 float v = ((float)py + rng.next()) / (float)(a.height - 1);
                 r = cameraRay(sc, u, v, rng);
-                thr = V3{1.0f, 1.0f, 1.0f};
-                depth = a.max_depth;
-                if (depth <= 0) {
+                setThr(V3{1.0f, 1.0f, 1.0f});
+                setDepth(a.max_depth);
+                if (a.max_depth <= 0) {
                     if (COUNT) st.v[C_CUTOFF]++;
                     endPath(V3{0.0f, 0.0f, 0.0f});
                 } else {
