@@ -296,12 +296,15 @@ int rt_clear(rt_context* ctx);
  * colour buffer (12 bytes per pixel sample of the launch, allocated on first use and grown on
  * demand; calls that would need more than RT_COLORS_MB megabytes, default 4096, run as several
  * launches) and is added per pixel in sample order, so the sums have the bits of the reference's
- * sequential `pixelColor +=`.  Asynchronous on the context's stream unless the buffer must grow. */
+ * sequential `pixelColor +=`.  Launches of 48 M samples and more of a scene whose tables fit LDS run as two
+ * kernels -- the camera rays of a tile walked together, then the loop over the surviving paths -- and keep 48
+ * more bytes per pixel sample for the path records between them (RT_RECORDS_MB, default 6400, cuts the launch;
+ * RT_TWO_PASS=0 / 1: never / always).  Asynchronous on the context's stream unless a buffer must grow. */
 int rt_render(rt_context* ctx, int first_sample, int n_samples, int max_depth);
 /* rt_render() for callers that cannot allocate device memory: code under HIP graph capture, tight
  * serving loops, harnesses that forbid hipMalloc.  No counterpart in the reference.  Same work,
- * same bits as rt_render(), but the per-sample colour buffer and the queue counter live in a fixed
- * array inside the library (64 MiB + 256 bytes per GPU in use, held until the process ends), so the
+ * same bits as rt_render(), but the per-sample colour buffer and the queue's counters live in a fixed
+ * array inside the library (64 MiB + 4 KiB per GPU in use, held until the process ends), so the
  * call allocates and frees nothing; a sample range that needs more colour space than that runs as
  * several launches.  Fails with RT_ERR_LIMIT when the context's share of the frame has more than
  * rt_noalloc_max_pixels() pixel slots (5,592,405 = 64 MiB / 12 bytes: one sample of every slot must fit).  Every call on

@@ -233,10 +233,16 @@ int launch(rt_context* ctx, rt::RenderArgs& a, bool count, const Workspace* fixe
     }
     // Two passes (primaryPass, then the loop over its path records) for scenes whose tables are in LDS: the camera
     // rays of a tile are walked together, a full wave at a time, and the loop's SHADE and NEWPATH become one phase
-    // (bench workload 18.7 ms against 19.95 for the single pass; RT_TWO_PASS=0 selects that).  Costs 48 bytes of
-    // records per pixel sample of a launch (RT_RECORDS_MB, default 6400, bounds them).  Never for the fixed-scratch
-    // entry point or with the reference-order walk forced.
-    const bool twoPass = !fixed && ctx->use_lds && !a.sc.force_ref && a.max_depth >= 1 && envInt("RT_TWO_PASS", 1) != 0;
+    // (bench workload 18.7 ms against 19.95 for the single pass).  Costs 48 bytes of records per pixel sample of a
+    // launch (RT_RECORDS_MB, default 6400, bounds them).  Never for the fixed-scratch entry point or with the
+    // reference-order walk forced.  A second kernel costs a start-up and a tail of its own (a path of 50 bounces takes
+    // 0.3-0.4 ms whatever else the GPU does), so small launches stay with the single pass: 1080p x 16 spp 5.55 against
+    // 5.73 ms, 1200x675 x 10 spp 2.05 against 2.41; the lines cross at about 45 M samples.  RT_TWO_PASS=1 / 0: always /
+    // never.
+    constexpr long long kTwoPassMinSamples = 48000000ll;
+    const int twoPassKnob = envInt("RT_TWO_PASS", -1);
+    const bool twoPass = !fixed && ctx->use_lds && !a.sc.force_ref && a.max_depth >= 1 && twoPassKnob != 0 &&
+                         (twoPassKnob > 0 || nSlots * (long long)a.n_samples >= kTwoPassMinSamples);
     constexpr size_t kRecordBytes = 48;
     if (twoPass) budget = std::min(budget, ((size_t)std::max(16, envInt("RT_RECORDS_MB", 6400)) << 20) / kRecordBytes * sizeof(rt::Radiance));
     size_t maxSamples = std::max<size_t>(1, budget / ((size_t)nSlots * sizeof(rt::Radiance)));
