@@ -75,6 +75,8 @@ __shared__ float g_worldRay[6][WF_MAX_THREADS];
 // left -- lives here, read and written where it is used, instead of in registers carried through the walk and
 // through the scatter code.
 __shared__ float g_parked[5][WF_MAX_THREADS];
+// ... and what a wave knows about its current chunk (sample, corner pixel; -1: the tile lies outside the image)
+__shared__ int g_chunkAt[WF_MAX_THREADS / 64][4];
 #ifndef RT_PARK
 #define RT_PARK 1
 #endif
@@ -1154,6 +1156,7 @@ __global__ void __launch_bounds__(WF_MAX_THREADS, LDS ? WF_WAVES_LDS : (INST ? W
             depthKept = d;
     };
     setDepth(0);
+    if (PARK && lane == 0) g_chunkAt[threadIdx.x >> 6][3] = a.max_depth;
     Rng rng{0u, 0u};
     Ray r{{0.f, 0.f, 0.f}, {0.f, 0.f, 1.f}};
     float invx = 0.f, invy = 0.f, invz = 0.f;
@@ -1692,10 +1695,19 @@ __global__ void __launch_bounds__(WF_MAX_THREADS, LDS ? WF_WAVES_LDS : (INST ? W
                     int base = (a.rank - ty) % a.world;
                     if (base < 0) base += a.world;
                     const int tx = base + k * a.world;
-                    chunkSample = a.first_sample + sIdx;
-                    chunkX0 = tx * kTile;
-                    chunkY0 = ty * kTile;
-                    chunkInside = tx < a.tiles_x;
+                    if (PARK) {
+                        if (lane == 0) {
+                            int* at = g_chunkAt[threadIdx.x >> 6];
+                            at[0] = a.first_sample + sIdx;
+                            at[1] = tx < a.tiles_x ? tx * kTile : -1;
+                            at[2] = ty * kTile;
+                        }
+                    } else {
+                        chunkSample = a.first_sample + sIdx;
+                        chunkX0 = tx * kTile;
+                        chunkY0 = ty * kTile;
+                        chunkInside = tx < a.tiles_x;
+                    }
                 }
             }
             lap(T_REFILL);
@@ -1734,6 +1746,13 @@ __global__ void __launch_bounds__(WF_MAX_THREADS, LDS ? WF_WAVES_LDS : (INST ? W
                     }
                 }
             } else {
+            if (PARK) {  // (written by this wave's first lane; a wave's LDS accesses take effect in program order)
+                const int* at = g_chunkAt[threadIdx.x >> 6];
+                chunkSample = at[0];
+                chunkX0 = at[1];
+                chunkY0 = at[2];
+                chunkInside = chunkX0 >= 0;
+            }
             const int px = chunkX0 + (l & 7), py = chunkY0 + (l >> 3);
             if (want & (chunk >= 0) & (l < 64) & chunkInside & (px < a.width) & (py < a.height)) {
                 setUnit((unsigned int)chunk * 64u + (unsigned int)l);
@@ -1744,8 +1763,9 @@ __global__ void __launch_bounds__(WF_MAX_THREADS, LDS ? WF_WAVES_LDS : (INST ? W
                 float v = ((float)py + rng.next()) / (float)(a.height - 1);
                 r = cameraRay(sc, u, v, rng);
                 setThr(V3{1.0f, 1.0f, 1.0f});
-                setDepth(a.max_depth);
-                if (a.max_depth <= 0) {
+                const int maxDepth = PARK ? g_chunkAt[threadIdx.x >> 6][3] : a.max_depth;
+                setDepth(maxDepth);
+                if (maxDepth <= 0) {
                     if (COUNT) st.v[C_CUTOFF]++;
                     endPath(V3{0.0f, 0.0f, 0.0f});
                 } else {
