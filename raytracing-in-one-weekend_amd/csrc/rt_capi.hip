@@ -214,7 +214,7 @@ int launch(rt_context* ctx, rt::RenderArgs& a, bool count, const Workspace* fixe
     // big); tables in global memory: eight 256-thread workgroups = 8 waves per SIMD (see renderWavefront)
     const int defThreads = ctx->use_lds ? 512 : 256;
     int wfThreads = envInt("RT_THREADS", defThreads);
-    if (wfThreads < 64 || wfThreads > WF_MAX_THREADS || wfThreads % 64 != 0) wfThreads = defThreads;
+    if (wfThreads < 64 || wfThreads > (ctx->use_lds ? WF_MAX_THREADS : WF_GLOBAL_THREADS) || wfThreads % 64 != 0) wfThreads = defThreads;
     const int wfWaves = wfThreads / 64;
     const int perCu = !ctx->use_lds ? 8 * 256 / wfThreads : (ctx->lds_need > kLdsThreeGroups ? 2 : 3);
     const int maxBlocks = ctx->n_cus * envInt("RT_BLOCKS_PER_CU", perCu);

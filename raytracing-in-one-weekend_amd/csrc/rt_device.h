@@ -104,7 +104,9 @@ constexpr size_t kQueueBytes = 4096;
 
 constexpr int kTile = 8;  // one wave64 = one 8x8 pixel tile
 
-// largest workgroup the persistent kernel is compiled for (its launch bounds)
+// workgroups of the persistent loop: at most WF_MAX_THREADS (the kernel's launch bounds), and at most WF_GLOBAL_THREADS when the scene's tables
+// are read from global memory (per-lane LDS arrays of those builds are sized for that)
+#define WF_GLOBAL_THREADS 256
 #ifndef WF_MAX_THREADS
 #define WF_MAX_THREADS 512
 #endif

@@ -70,13 +70,13 @@ __shared__ float g_texLut[256];
 
 // Instancing in the persistent loop: a lane's world-space ray (origin, direction) while the lane walks a prototype
 // in object space, one slot per thread (only the build for scenes with instances refers to it)
-__shared__ float g_worldRay[6][WF_MAX_THREADS];
+__shared__ float g_worldRay[6][WF_GLOBAL_THREADS];
 // Scenes in global memory: the part of a lane's state that only SHADE and NEWPATH touch -- throughput, unit, depth
 // left -- lives here, read and written where it is used, instead of in registers carried through the walk and
 // through the scatter code.
-__shared__ float g_parked[5][WF_MAX_THREADS];
+__shared__ float g_parked[5][WF_GLOBAL_THREADS];
 // ... and what a wave knows about its current chunk (sample, corner pixel; -1: the tile lies outside the image)
-__shared__ int g_chunkAt[WF_MAX_THREADS / 64][4];
+__shared__ int g_chunkAt[WF_GLOBAL_THREADS / 64][4];
 #ifndef RT_PARK
 #define RT_PARK 1
 #endif
@@ -1127,7 +1127,7 @@ __global__ void __launch_bounds__(WF_MAX_THREADS, LDS ? WF_WAVES_LDS : (INST ? W
 
     int op = OP_NEWPATH;
     int idx = 0, p = 0;
-    constexpr bool PARK = RT_PARK && !LDS && !INST && !COUNT && !TIME;
+    constexpr bool PARK = RT_PARK && !LDS && !COUNT && !TIME;
     int depthKept = 0;
     unsigned int unitKept = 0;
     V3 thrKept{1.f, 1.f, 1.f};
@@ -2199,6 +2199,7 @@ __global__ void __launch_bounds__(256) resolveKernel(const float4* payloads, siz
 // ------------------------------------------------------------------ launch wrappers
 template <bool LDS, bool COUNT, bool TIME = false, int HAS = S_ALL, bool NMAP = false, bool ONEPHASE = false, bool INST = false>
 static hipError_t launchWavefrontT(const RenderArgs& a, int blocks, int threads, size_t shmem, hipStream_t stream) {
+    if (threads > (LDS ? WF_MAX_THREADS : WF_GLOBAL_THREADS)) return hipErrorInvalidValue;  // per-lane LDS arrays are sized for this
     (void)hipGetLastError();  // an earlier, unrelated failure must not be reported as this launch's
     if (LDS)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(renderWavefront<LDS, COUNT, TIME, HAS, NMAP, false, ONEPHASE, INST>),
