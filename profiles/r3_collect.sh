@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-3 evidence in one GPU job: bench profile (kernel trace + PMC passes), BASELINE configurations, memory
+# Evidence in one GPU job: bench profile (kernel trace + PMC passes), BASELINE configurations, memory
 # counters of the configurations read through the caches, scheduler statistics, operation ticks.
 # Usage (GPU box, repo root): bash profiles/r3_collect.sh
 set -u

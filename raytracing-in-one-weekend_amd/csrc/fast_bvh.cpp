@@ -29,6 +29,7 @@
 #include <cstring>
 #include <atomic>
 #include <limits>
+#include <mutex>
 #include <thread>
 
 #include "host_scene.h"
@@ -408,20 +409,26 @@ void Scene::buildFastStructure() {
     // square of the distance to the sphere) is covered by margin, not by a bound.
     const bool deferred = f.defer_search_build;  // the device builds the structure: only its inputs are prepared
     std::vector<PrimBox> prims;
-    if (!deferred) prims.reserve(spheres.size() + triangles.size());
     f.world_refs.clear();
-    f.world_refs.reserve(spheres.size() + triangles.size());
     for (int k = 0; k < 3; k++) {
         f.centroid_min[k] = std::numeric_limits<float>::infinity();
         f.centroid_max[k] = -std::numeric_limits<float>::infinity();
     }
+    // (the passes over all primitives below run in pieces on the builders' threads; minima and maxima are
+    // exact whatever the order, so the result does not depend on the thread count)
+    std::mutex fold;
     float extent = 0.0f;
     for (size_t i = 0; i < spheres.size(); i++)
         if (f.sphere_ord[i] >= 0)
             for (int k = 0; k < 3; k++) extent = std::max(extent, std::fabs(spheres[i].c[k]) + std::fabs(spheres[i].r));
-    for (size_t i = 0; i < triangles.size(); i++)
-        if (f.tri_ord[i] >= 0)
-            for (int k = 0; k < 9; k++) extent = std::max(extent, std::fabs(triangles[i].pos[k]));
+    parallelPieces(triangles.size(), [&](size_t first, size_t last) {
+        float e = 0.0f;
+        for (size_t i = first; i < last; i++)
+            if (f.tri_ord[i] >= 0)
+                for (int k = 0; k < 9; k++) e = std::max(e, std::fabs(triangles[i].pos[k]));
+        std::lock_guard<std::mutex> g(fold);
+        extent = std::max(extent, e);
+    });
     const float originFloor = extent * (1.01f / 2097152.0f);
     // The padding of a primitive box has two parts.  `base`: the rounding of the fused box test (above).
     // `far`: the inaccuracy of the reference's own hit test, which grows with the distance D between ray origin
@@ -465,10 +472,15 @@ void Scene::buildFastStructure() {
     for (size_t i = 0; i < triangles.size(); i++)
         if (f.tri_ord[i] >= 0) world.push_back({true, i});
     std::vector<float> base(world.size());
-    for (size_t w = 0; w < world.size(); w++) {
-        base[w] = basePad(primBox(world[w].first, world[w].second));
-        minPad = std::min(minPad, base[w]);
-    }
+    parallelPieces(world.size(), [&](size_t first, size_t last) {
+        float m = std::numeric_limits<float>::infinity();
+        for (size_t w = first; w < last; w++) {
+            base[w] = basePad(primBox(world[w].first, world[w].second));
+            m = std::min(m, base[w]);
+        }
+        std::lock_guard<std::mutex> g(fold);
+        minPad = std::min(minPad, m);
+    });
     f.far_spheres = f.far_tris = 0;
     f.far_rmin = 0.0f;
     double farC[3] = {0, 0, 0}, farR = 0.0, rmin = std::numeric_limits<double>::infinity();
@@ -513,22 +525,36 @@ void Scene::buildFastStructure() {
     f.far_rmin = f.far_spheres ? (float)rmin : 0.0f;
     f.far_typical = (float)dTyp;
     // pass 2: the padded boxes
-    for (size_t w = 0; w < world.size(); w++) {
-        PrimBox b = primBox(world[w].first, world[w].second);
-        f.world_refs.push_back(b.ref);
+    f.world_refs.resize(world.size());
+    if (!deferred) prims.resize(world.size());
+    parallelPieces(world.size(), [&](size_t first, size_t last) {
+        float cmn[3], cmx[3];
         for (int k = 0; k < 3; k++) {
-            const float c = 0.5f * (b.mn[k] + b.mx[k]);
-            f.centroid_min[k] = std::min(f.centroid_min[k], c);
-            f.centroid_max[k] = std::max(f.centroid_max[k], c);
+            cmn[k] = std::numeric_limits<float>::infinity();
+            cmx[k] = -std::numeric_limits<float>::infinity();
         }
-        const double far = world[w].first ? kTriErr * dTyp : phantomSphere(std::fabs((double)spheres[world[w].second].r), dTyp);
-        const float d = (float)((double)base[w] + far * 1.01);
+        for (size_t w = first; w < last; w++) {
+            PrimBox b = primBox(world[w].first, world[w].second);
+            f.world_refs[w] = b.ref;
+            for (int k = 0; k < 3; k++) {
+                const float c = 0.5f * (b.mn[k] + b.mx[k]);
+                cmn[k] = std::min(cmn[k], c);
+                cmx[k] = std::max(cmx[k], c);
+            }
+            const double far = world[w].first ? kTriErr * dTyp : phantomSphere(std::fabs((double)spheres[world[w].second].r), dTyp);
+            const float d = (float)((double)base[w] + far * 1.01);
+            for (int k = 0; k < 3; k++) {
+                b.mn[k] -= d;
+                b.mx[k] += d;
+            }
+            if (!deferred) prims[w] = b;
+        }
+        std::lock_guard<std::mutex> g(fold);
         for (int k = 0; k < 3; k++) {
-            b.mn[k] -= d;
-            b.mx[k] += d;
+            f.centroid_min[k] = std::min(f.centroid_min[k], cmn[k]);
+            f.centroid_max[k] = std::max(f.centroid_max[k], cmx[k]);
         }
-        if (!deferred) prims.push_back(b);
-    }
+    });
     f.fast_min_pad = minPad;
     f.pad_floor = originFloor;
     if (deferred && !f.world_refs.empty()) return;

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <atomic>
 #include <map>
+#include <mutex>
 #include <thread>
 #include "host_scene.h"
 #include "image_decode.h"
@@ -579,9 +580,10 @@ unsigned buildThreads() {
 }
 
 std::vector<Scene::BoxedObj> Scene::withBoxes(const std::vector<Obj>& objs) const {
-    std::vector<BoxedObj> out;
-    out.reserve(objs.size());
-    for (const Obj& o : objs) out.push_back({o, objectBox(o)});
+    std::vector<BoxedObj> out(objs.size());
+    parallelPieces(objs.size(), [&](size_t from, size_t to) {
+        for (size_t i = from; i < to; i++) out[i] = {objs[i], objectBox(objs[i])};
+    });
     return out;
 }
 
@@ -609,14 +611,38 @@ int Scene::addMesh(const float* model16, int n_vertices, const float* positions,
     mesh.has_box_test = true;
     float mn[3] = {kInf, kInf, kInf}, mx[3] = {1e-8f, 1e-8f, 1e-8f};  // Mesh.cpp:16-21
     std::vector<Obj> tris;
-    tris.reserve(n_triangles);
-    int first = -1;
-    for (int f = 0; f < n_triangles; f++) {
+    const bool timing = std::getenv("RT_HOST_TIMING") && std::atoi(std::getenv("RT_HOST_TIMING")) != 0;
+    auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[add_mesh] %-41s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t0).count());
+        t0 = now;
+    };
+    // an index beyond the vertices refuses the mesh before anything of it has been taken in
+    {
+        std::atomic<bool> bad{false};
+        parallelPieces((size_t)n_triangles * 3, [&](size_t from, size_t to) {
+            for (size_t i = from; i < to; i++)
+                if (indices[i] >= (uint32_t)n_vertices) bad = true;
+        });
+        if (bad) return -1;
+    }
+    // The faces are independent of each other (pieces of them go to the builders' threads); the mesh's box is a
+    // minimum and a maximum, which come out the same in any order.
+    const size_t base = triangles.size();
+    const int first = n_triangles > 0 ? (int)base : -1;
+    triangles.resize(base + (size_t)n_triangles);
+    tris.resize((size_t)n_triangles);
+    flat.valid = false;
+    std::mutex fold;
+    parallelPieces((size_t)n_triangles, [&](size_t from, size_t to) {
+      float lmn[3] = {kInf, kInf, kInf}, lmx[3] = {1e-8f, 1e-8f, 1e-8f};
+      for (size_t f = from; f < to; f++) {
         float pos[9], nrm[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         float uv[6] = {0.0f, 0.0f, 0.1f, 0.0f, 0.5f, 1.0f};  // Mesh.cpp:122-124 defaults
         for (int k = 0; k < 3; k++) {
             uint32_t vi = indices[3 * f + k];
-            if (vi >= (uint32_t)n_vertices) return -1;
             mulPoint(model16, &positions[3 * vi], 1.0f, &pos[3 * k]);  // Mesh.cpp:145-147
             if (uvs) {
                 uv[2 * k] = uvs[2 * vi];
@@ -630,16 +656,25 @@ int Scene::addMesh(const float* model16, int n_vertices, const float* positions,
                     nrm[3 * k + r] = (inv[r * 4 + 0] * n[0] + inv[r * 4 + 1] * n[1]) + inv[r * 4 + 2] * n[2];
             }
         }
-        int id = newTriangle(pos, nrm, uv, tri_materials ? tri_materials[f] : mat);
-        if (first < 0) first = id;
-        tris.push_back({Obj::TRIANGLE, id});
+        HostTriangle& t = triangles[base + f];
+        std::memcpy(t.pos, pos, sizeof t.pos);
+        std::memcpy(t.nrm, nrm, sizeof t.nrm);
+        std::memcpy(t.uv, uv, sizeof t.uv);
+        t.mat = tri_materials ? tri_materials[f] : mat;
+        tris[f] = {Obj::TRIANGLE, (int)(base + f)};
         for (int a = 0; a < 3; a++) {  // Mesh.cpp:165-207
             for (int k = 0; k < 3; k++)
-                if (pos[3 * k + a] < mn[a]) mn[a] = pos[3 * k + a];
+                if (pos[3 * k + a] < lmn[a]) lmn[a] = pos[3 * k + a];
             for (int k = 0; k < 3; k++)
-                if (pos[3 * k + a] > mx[a]) mx[a] = pos[3 * k + a];
+                if (pos[3 * k + a] > lmx[a]) lmx[a] = pos[3 * k + a];
         }
-    }
+      }
+      std::lock_guard<std::mutex> g(fold);
+      for (int a = 0; a < 3; a++) {
+          if (lmn[a] < mn[a]) mn[a] = lmn[a];
+          if (lmx[a] > mx[a]) mx[a] = lmx[a];
+      }
+    });
     for (int a = 0; a < 3; a++) {
         mesh.box.mn[a] = mn[a];
         mesh.box.mx[a] = mx[a];
@@ -648,8 +683,11 @@ int Scene::addMesh(const float* model16, int n_vertices, const float* positions,
     Composite bvh;
     bvh.kind = Composite::BVH;
     bvh.has_box_test = true;
+    lap("triangles (Mesh::processMesh)");
     std::vector<BoxedObj> boxed = withBoxes(tris);
+    lap("their boxes");
     bvh.root = buildBvh(bvh, boxed, 0, boxed.size(), max_depth);
+    lap("BVHNode over them");
     bvh.box = bvh.nodes[bvh.root].box;
     composites.push_back(std::move(bvh));
     mesh.objs.push_back({Obj::COMPOSITE, (int)composites.size() - 1});
@@ -1149,6 +1187,15 @@ void Scene::flatten() {
         if (flat.fast_stale) buildFastStructure();
         return;
     }
+    // RT_HOST_TIMING=1: the two halves of this function on stderr
+    const bool timing = std::getenv("RT_HOST_TIMING") && std::atoi(std::getenv("RT_HOST_TIMING")) != 0;
+    auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[flatten] %-42s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t0).count());
+        t0 = now;
+    };
     flat.nodes.clear();
     flat.prim_refs.clear();
     flat.max_leaf = 0;
@@ -1167,7 +1214,9 @@ void Scene::flatten() {
             flat.proto_range.push_back((int32_t)(flat.nodes.size() / 8));
         }
     }
+    lap("reference-order entries");
     buildFastStructure();
+    lap(flat.defer_search_build ? "guard tables, inputs of the device build" : "guard tables, search structure");
     flat.valid = true;
 }
 

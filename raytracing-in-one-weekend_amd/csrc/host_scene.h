@@ -1,10 +1,12 @@
 // Host-side scene construction and the BVH flatten step (no device code here).
 // R/ = /root/reference/Raytracing-In-A-Weekend/ in the citations below.
 #pragma once
+#include <algorithm>
 #include <atomic>
 #include <cstdint>
 #include <random>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace rt {
@@ -138,6 +140,24 @@ struct Camera22 {
 };
 
 unsigned buildThreads();  // threads the host-side builders may use
+
+// fn(first, last) over [0, n) in contiguous pieces on the builders' threads (small ranges: the caller's thread)
+template <class F>
+void parallelPieces(size_t n, F fn) {
+    const unsigned threads = buildThreads();
+    if (n < (1u << 16) || threads < 2) {
+        fn((size_t)0, n);
+        return;
+    }
+    const size_t piece = (n + threads - 1) / threads;
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < threads; t++) {
+        const size_t a = std::min(n, t * piece), b = std::min(n, a + piece);
+        if (a < b) pool.emplace_back([=] { fn(a, b); });
+    }
+    fn((size_t)0, std::min(n, piece));
+    for (auto& th : pool) th.join();
+}
 
 // Tangent and bitangent of a triangle from its positions (9 floats) and texture coordinates (6 floats):
 //   T = f (dv2 e1 - dv1 e2),  B = f (-du2 e1 + du1 e2),  f = 1 / (du1 dv2 - du2 dv1),

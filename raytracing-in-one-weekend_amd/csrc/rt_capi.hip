@@ -5,14 +5,18 @@
 
 #include <limits>
 
+#include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/rtiow_hip.h"
@@ -118,17 +122,55 @@ int envInt(const char* name, int dflt) {
     return v ? std::atoi(v) : dflt;
 }
 
-template <class T>
-int devUpload(rt_context* ctx, const std::vector<T>& host, const T** out) {
-    size_t bytes = std::max<size_t>(host.size() * sizeof(T), 16);
+// `count` elements of T from host memory into a device allocation the context owns
+template <class T, class S>
+int devUploadRaw(rt_context* ctx, const S* host, size_t count, const T** out) {
+    size_t bytes = std::max<size_t>(count * sizeof(T), 16);
     void* d = nullptr;
     HIP_TRY(hipMalloc(&d, bytes));
     ctx->scene_allocs.push_back(d);
-    if (!host.empty()) HIP_TRY(hipMemcpyAsync(d, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    if (count) HIP_TRY(hipMemcpyAsync(d, host, count * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     *out = reinterpret_cast<const T*>(d);
     return RT_OK;
 }
+
+template <class T>
+int devUpload(rt_context* ctx, const std::vector<T>& host, const T** out) {
+    return devUploadRaw<T, T>(ctx, host.data(), host.size(), out);
+}
+
+// fn(first, last) over [0, n) in contiguous pieces on up to 16 threads (RT_BUILD_THREADS, as the host-side
+// builders); small ranges run on the caller's thread
+template <class F>
+void parallelRanges(size_t n, F fn) {
+    unsigned threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    if (const char* e = std::getenv("RT_BUILD_THREADS")) threads = (unsigned)std::max(1, std::atoi(e));
+    if (n < (1u << 16) || threads < 2) {
+        fn((size_t)0, n);
+        return;
+    }
+    const size_t piece = (n + threads - 1) / threads;
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < threads; t++) {
+        const size_t a = std::min(n, t * piece), b = std::min(n, a + piece);
+        if (a < b) pool.emplace_back([=] { fn(a, b); });
+    }
+    fn((size_t)0, std::min(n, piece));
+    for (auto& th : pool) th.join();
+}
+
+// RT_HOST_TIMING=1: the phases of rt_upload_scene() on stderr (host preparation, copies, device build)
+struct PhaseClock {
+    bool on = envInt("RT_HOST_TIMING", 0) != 0;
+    std::chrono::steady_clock::time_point last = std::chrono::steady_clock::now();
+    void lap(const char* what) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[rt_upload_scene] %-34s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - last).count());
+        last = now;
+    }
+};
 
 void freeScene(rt_context* ctx) {
     for (void* p : ctx->scene_allocs) (void)hipFree(p);
@@ -705,10 +747,12 @@ int rt_upload_scene(rt_context* ctx, rt_scene* s) {
     const size_t autoMin = (size_t)std::max(1, envInt("RT_DEVICE_BUILD_MIN", 2000000));
     const bool wantDevice = ctx->device_build == 1 ||
                             (ctx->device_build < 0 && !hostBuiltAlready && sc.spheres.size() + sc.triangles.size() >= autoMin);
+    PhaseClock clock;
     sc.flat.defer_search_build = wantDevice;
     sc.flatten();
     if (!wantDevice && sc.flat.fast_nodes.empty()) sc.buildFastStructure();
     sc.flat.defer_search_build = false;
+    clock.lap(wantDevice ? "flatten (inputs of a device build)" : "flatten + host build");
     const bool deviceBuild = wantDevice && !sc.flat.world_refs.empty();
     for (const auto& m : sc.materials)
         if (m.kind == RT_MAT_PBR && (m.tex_d < 0 || m.tex_d >= (int)sc.textures.size()))
@@ -719,21 +763,25 @@ int rt_upload_scene(rt_context* ctx, rt_scene* s) {
     if ((uint32_t)nNodes >= rt::kNodeSkipMask) return fail(RT_ERR_LIMIT, "too many BVH entries");
     // the search structure's fused box test multiplies plane coordinates by reciprocal directions
     // of up to 1e30: beyond 1e7 that could overflow, so such scenes walk the reference-order array
-    bool hugeCoords = false;
+    std::atomic<bool> hugeSeen{false};
     for (const auto& sp : sc.spheres)
-        for (int k = 0; k < 3; k++) hugeCoords = hugeCoords || !(std::fabs(sp.c[k]) + std::fabs(sp.r) < 1e7f);
-    for (const auto& t : sc.triangles)
-        for (int k = 0; k < 9; k++) hugeCoords = hugeCoords || !(std::fabs(t.pos[k]) < 1e7f);
+        for (int k = 0; k < 3; k++)
+            if (!(std::fabs(sp.c[k]) + std::fabs(sp.r) < 1e7f)) hugeSeen = true;
     std::vector<float4> spheres(sc.spheres.size());
     std::vector<int> sphereMat(sc.spheres.size());
     for (size_t i = 0; i < sc.spheres.size(); i++) {
         spheres[i] = make_float4(sc.spheres[i].c[0], sc.spheres[i].c[1], sc.spheres[i].c[2], sc.spheres[i].r);
         sphereMat[i] = sc.spheres[i].mat;
     }
-    std::vector<float4> triI(sc.triangles.size() * 3), triS(sc.triangles.size() * 4);
-    std::vector<int> triMat(sc.triangles.size());
-    for (size_t i = 0; i < sc.triangles.size(); i++) {
+    // (the staging arrays are filled by the threads that first touch their pages)
+    const size_t nTri = sc.triangles.size();
+    std::unique_ptr<float4[]> triI(new float4[nTri * 3 + 1]), triS(new float4[nTri * 4 + 1]);
+    std::unique_ptr<int[]> triMat(new int[nTri + 1]);
+    parallelRanges(nTri, [&](size_t first, size_t last) {
+      bool huge = false;
+      for (size_t i = first; i < last; i++) {
         const rt::HostTriangle& t = sc.triangles[i];
+        for (int k = 0; k < 9; k++) huge = huge || !(std::fabs(t.pos[k]) < 1e7f);
         // edge1 = v1 - v0, edge2 = v2 - v0 (R/src/Core/Hittable.h:64-65), computed once here
         triI[3 * i] = make_float4(t.pos[0], t.pos[1], t.pos[2], 0.f);
         triI[3 * i + 1] = make_float4(t.pos[3] - t.pos[0], t.pos[4] - t.pos[1], t.pos[5] - t.pos[2], 0.f);
@@ -743,20 +791,25 @@ int rt_upload_scene(rt_context* ctx, rt_scene* s) {
         triS[4 * i + 2] = make_float4(t.nrm[6], t.nrm[7], t.nrm[8], t.uv[2]);
         triS[4 * i + 3] = make_float4(t.uv[3], t.uv[4], t.uv[5], 0.f);
         triMat[i] = t.mat;
-    }
+      }
+      if (huge) hugeSeen = true;
+    });
+    const bool hugeCoords = hugeSeen;
     // Tangent frame per triangle, for scenes with normal mapping switched on: the uv-delta construction of
     // R/src/Core/Hittable.h:110-125 with each uv difference paired with the edge to the same vertex
     // (the reference pairs them crosswise, one reason its mapped normal "doesn't work properly yet").
     std::vector<float4> triF;
     if (sc.normal_mapping) {
         triF.resize(sc.triangles.size() * 2);
-        for (size_t i = 0; i < sc.triangles.size(); i++) {
-            const rt::HostTriangle& t = sc.triangles[i];
-            float tan[3], bit[3];
-            const bool ok = rt::tangentFrame(t.pos, t.uv, tan, bit);
-            triF[2 * i] = make_float4(tan[0], tan[1], tan[2], ok ? 1.0f : 0.0f);
-            triF[2 * i + 1] = make_float4(bit[0], bit[1], bit[2], 0.0f);
-        }
+        parallelRanges(nTri, [&](size_t first, size_t last) {
+            for (size_t i = first; i < last; i++) {
+                const rt::HostTriangle& t = sc.triangles[i];
+                float tan[3], bit[3];
+                const bool ok = rt::tangentFrame(t.pos, t.uv, tan, bit);
+                triF[2 * i] = make_float4(tan[0], tan[1], tan[2], ok ? 1.0f : 0.0f);
+                triF[2 * i + 1] = make_float4(bit[0], bit[1], bit[2], 0.0f);
+            }
+        });
     }
     std::vector<float4> mats(sc.materials.size() * 2);
     for (size_t i = 0; i < sc.materials.size(); i++) {
@@ -775,17 +828,18 @@ int rt_upload_scene(rt_context* ctx, rt_scene* s) {
         size_t n = (size_t)t.w * t.h, base = texels.size();
         if (base + n > (size_t)0x7FFFFFFF) return fail(RT_ERR_LIMIT, "texture pool beyond 2^31 texels");
         texels.resize(base + n);
-        for (size_t p = 0; p < n; p++)
-            texels[base + p] = (uint32_t)t.rgb[3 * p] | ((uint32_t)t.rgb[3 * p + 1] << 8) | ((uint32_t)t.rgb[3 * p + 2] << 16);
+        parallelRanges(n, [&](size_t first, size_t last) {
+            for (size_t p = first; p < last; p++)
+                texels[base + p] = (uint32_t)t.rgb[3 * p] | ((uint32_t)t.rgb[3 * p + 1] << 8) | ((uint32_t)t.rgb[3 * p + 2] << 16);
+        });
     }
     std::vector<float> lut(256);  // applied per channel at sampling time
     rt_texture_lut256(lut.data());
 
+    clock.lap("staging of primitives and texels");
     rt::DevScene d{};
     int rc;
-    std::vector<float4> nodes(sc.flat.nodes.size() / 4);
-    std::memcpy(nodes.data(), sc.flat.nodes.data(), sc.flat.nodes.size() * 4);
-    if ((rc = devUpload(ctx, nodes, &d.nodes))) return rc;
+    if ((rc = devUploadRaw<float4>(ctx, sc.flat.nodes.data(), sc.flat.nodes.size() / 4, &d.nodes))) return rc;
     if ((rc = devUpload(ctx, sc.flat.prim_refs, &d.prim_refs))) return rc;
     // Scenes whose tables stay in global memory walk the direction-ordered copies of the search
     // structure (same decision as for LDS below, taken here on the counts alone).
@@ -803,10 +857,8 @@ int rt_upload_scene(rt_context* ctx, rt_scene* s) {
         octants = !deviceBuild && !fitsLds && sc.flat.fast_oct_stride > 0 && envInt("RT_OCTANTS", 1) != 0;
     }
     const std::vector<uint32_t>& fastSrc = octants ? sc.flat.fast_oct : sc.flat.fast_nodes;
-    std::vector<float4> fastNodes(fastSrc.size() / 4);
-    std::memcpy(fastNodes.data(), fastSrc.data(), fastSrc.size() * 4);
     if (!deviceBuild) {
-        if ((rc = devUpload(ctx, fastNodes, &d.fast_nodes))) return rc;
+        if ((rc = devUploadRaw<float4>(ctx, fastSrc.data(), fastSrc.size() / 4, &d.fast_nodes))) return rc;
         if ((rc = devUpload(ctx, sc.flat.fast_refs, &d.fast_refs))) return rc;
     }
     d.fast_oct_stride = octants ? sc.flat.fast_oct_stride : 0;
@@ -816,8 +868,8 @@ int rt_upload_scene(rt_context* ctx, rt_scene* s) {
     if ((rc = devUpload(ctx, sc.flat.node_outer, &d.node_outer))) return rc;
     if ((rc = devUpload(ctx, spheres, &d.spheres))) return rc;
     if ((rc = devUpload(ctx, sphereMat, &d.sphere_mat))) return rc;
-    if ((rc = devUpload(ctx, triI, &d.tri_isect))) return rc;
-    if ((rc = devUpload(ctx, triS, &d.tri_shade))) return rc;
+    if ((rc = devUploadRaw<float4>(ctx, triI.get(), nTri * 3, &d.tri_isect))) return rc;
+    if ((rc = devUploadRaw<float4>(ctx, triS.get(), nTri * 4, &d.tri_shade))) return rc;
     if ((rc = devUpload(ctx, triF, &d.tri_frame))) return rc;
     d.normal_mapping = sc.normal_mapping ? 1 : 0;
     d.has_pbr = 0;
@@ -826,7 +878,7 @@ int rt_upload_scene(rt_context* ctx, rt_scene* s) {
         d.has_pbr |= m.kind == 4 ? 1 : 0;
         d.has_dielectric |= m.kind == 2 ? 1 : 0;
     }
-    if ((rc = devUpload(ctx, triMat, &d.tri_mat))) return rc;
+    if ((rc = devUploadRaw<int>(ctx, triMat.get(), nTri, &d.tri_mat))) return rc;
     if ((rc = devUpload(ctx, mats, &d.materials))) return rc;
     if ((rc = devUpload(ctx, texels, &d.texels))) return rc;
     if ((rc = devUpload(ctx, texDesc, &d.tex_desc))) return rc;
@@ -849,6 +901,7 @@ int rt_upload_scene(rt_context* ctx, rt_scene* s) {
     d.n_prim_refs = (int)sc.flat.prim_refs.size();
     d.n_fast_nodes = (int)(fastSrc.size() / 8);
     d.n_fast_refs = (int)sc.flat.fast_refs.size();
+    clock.lap("copies to the device");
     if (deviceBuild) {
         // the search structure is built where the primitives already are (csrc/device_bvh.hip)
         const uint32_t* dWorld = nullptr;
@@ -878,6 +931,7 @@ int rt_upload_scene(rt_context* ctx, rt_scene* s) {
         d.n_fast_nodes = stride > 0 ? 8 * stride : nEntries;
         d.fast_oct_stride = stride;
         d.n_fast_refs = (int)sc.flat.world_refs.size();
+        clock.lap("device build");
     }
     d.force_ref = (ctx->force_ref || hugeCoords || !sc.instances.empty()) ? 1 : 0;
     d.origin_limit = sc.flat.fast_min_pad * 2097152.0f;  // 2^21, see buildFastStructure()

@@ -1067,8 +1067,9 @@ __device__ __forceinline__ int popc64(unsigned long long m) {
 }
 
 // Occupancy.  Tables in LDS: 512-thread workgroups, three per CU = 6 waves per SIMD (80 registers per lane).
-// Measured on the cover scene: 4 waves per SIMD 37.6 ms, 6 waves 33.1 ms, and at the end of round 2 (25.7 ms with 6)
-// 7 waves 28.1 ms, 8 waves 28.4 ms: the LDS-resident loop is issue-bound and more waves only add contention.
+// Measured on the cover scene: 4 waves per SIMD 37.6 ms, 6 waves 33.1 ms; later, at 25.7 ms with 6, 7 waves 28.1 ms
+// and 8 waves 28.4 ms; at 20.0-20.6 ms with 6, 5 / 7 / 8 waves 24.2 / 24.5 / 25.9 ms: the LDS-resident loop is
+// issue-bound and more waves only add contention.
 // Tables in global memory: 8 waves per SIMD (64 registers per lane), 256-thread workgroups, eight per CU -- there
 // the loads go to L1 / L2 and two more waves hide their latency: Cornell + vase 265.8 -> 239.8 ms, 1 M triangles
 // 60.3 -> 58.5 ms, 10 M triangles unchanged (142 ms).

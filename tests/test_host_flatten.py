@@ -209,15 +209,20 @@ def test_empty_world_flattens_to_one_boxless_entry(rt):
     assert d["nodes"][0, 3] == ((1 << 30) | 1) and d["nodes"][0, 7] == 0xFFFFFFFF
 
 
-def test_threaded_build_equals_the_serial_one_and_the_oracle(rt, orc, monkeypatch):
+@pytest.mark.parametrize("ties", [False, True])
+def test_threaded_build_equals_the_serial_one_and_the_oracle(rt, orc, monkeypatch, ties):
     """Ranges of 32,768 objects and more are built by several threads (both the reference-order BVH,
-    whose axis draws are made up front in pre-order, and the search structure).  The result must not
-    depend on the number of threads, and the reference-order arrays must still be the oracle's."""
+    whose axis draws are made up front in pre-order, and the search structure).  The result must not depend on the
+    number of threads, and the reference-order arrays must still be the oracle's -- also when most keys are equal
+    (`ties`: centres on a coarse grid, one radius), where the order std::sort leaves equal keys in decides the tree."""
     def build(s):
         m = s.add_material(0, (0.5, 0.5, 0.5))
         rr = np.random.RandomState(17)
         c = (rr.rand(70000, 3) * 1000).astype(np.float32)
         rad = (0.5 + 3 * rr.rand(70000)).astype(np.float32)
+        if ties:
+            c = np.floor(c / 25).astype(np.float32) * 25
+            rad[:] = 2.0
         for i in range(70000):
             s.add_sphere(c[i], float(rad[i]), m)
         s.wrap_bvh()
