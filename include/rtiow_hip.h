@@ -414,8 +414,9 @@ int rt_count(rt_context* ctx, int first_sample, int n_samples, int max_depth, rt
 
 /* Diagnostics of the wavefront scheduler, filled by the last rt_count(): 7 pairs {wave-level
  * executions, lanes that took part}: the times each operation was voted in (search-structure box
- * test, primitive test, shade, new path, one unused pair), then the box-test steps inside those
- * votes, then the votes for the reference-order box test.  No reference counterpart. */
+ * test, primitive test, shade, new path), the wave-uniform walk steps of a two-pass launch's first
+ * pass, then the box-test steps inside the loop's votes, then the votes for the reference-order box
+ * test.  No reference counterpart. */
 int rt_sched_stats(rt_context* ctx, uint64_t* out14);
 
 /* Milliseconds the kernels of the last rt_render() took on the device (HIP events on the

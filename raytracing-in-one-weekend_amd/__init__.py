@@ -495,7 +495,7 @@ class Context:
     def sched_stats(self):
         out = np.zeros(14, np.uint64)
         _check(lib.rt_sched_stats(self.h, _p(out)))
-        names = ("box_votes", "prim", "shade", "newpath", "unused", "box_steps", "refbox_votes")
+        names = ("box_votes", "prim", "shade", "newpath", "first_pass_steps", "box_steps", "refbox_votes")
         return {n: (int(out[2 * i]), int(out[2 * i + 1])) for i, n in enumerate(names)}
 
     def last_render_ms(self):

@@ -2042,9 +2042,9 @@ __global__ void __launch_bounds__(WF_MAX_THREADS, WF_WAVES_LDS) primaryPass(Rend
                 make_float4(thr.z, __uint_as_float(rng.key), __uint_as_float(rng.counter), __uint_as_float(uw));
         }
     }
-    if (COUNT && lane == 0) {  // the uniform steps count as box steps of the scheduling statistics
-        atomicAdd(&a.counters[13 + 2 * 5], stepExec);
-        atomicAdd(&a.counters[14 + 2 * 5], stepLanes);
+    if (COUNT && lane == 0) {  // the uniform steps have a pair of their own in the scheduling statistics
+        atomicAdd(&a.counters[13 + 2 * 4], stepExec);
+        atomicAdd(&a.counters[14 + 2 * 4], stepLanes);
     }
     if (COUNT) {
         for (int i = 0; i < kNumStats; i++) {
