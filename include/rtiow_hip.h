@@ -294,11 +294,11 @@ int rt_clear(rt_context* ctx);
  * Random numbers are the reference shader's stateless hash keyed (x, y, sample, counter)
  * (R/assets/shaders/raytracer.comp:35-54).  Every sample's radiance passes through a device
  * colour buffer (12 bytes per pixel sample of the launch, allocated on first use and grown on
- * demand; calls that would need more than RT_COLORS_MB megabytes, default 4096, run as several
+ * demand; calls that would need more than RT_COLORS_MB megabytes, default 8192, run as several
  * launches) and is added per pixel in sample order, so the sums have the bits of the reference's
  * sequential `pixelColor +=`.  Launches of 48 M samples and more of a scene whose tables fit LDS run as two
  * kernels -- the camera rays of a tile walked together, then the loop over the surviving paths -- and keep 48
- * more bytes per pixel sample for the path records between them (RT_RECORDS_MB, default 6400, cuts the launch;
+ * more bytes per pixel sample for the path records between them (RT_RECORDS_MB, default 25600, cuts the launch;
  * RT_TWO_PASS=0 / 1: never / always).  Asynchronous on the context's stream unless a buffer must grow. */
 int rt_render(rt_context* ctx, int first_sample, int n_samples, int max_depth);
 /* rt_render() for callers that cannot allocate device memory: code under HIP graph capture, tight

@@ -263,9 +263,9 @@ int launch(rt_context* ctx, rt::RenderArgs& a, bool count, const Workspace* fixe
 
     // The kernel writes one radiance per pixel sample into the colour buffer and a second kernel
     // adds them per pixel in sample order; launches are cut so that the buffer stays within
-    // RT_COLORS_MB (default 4096) and the queue index within 32 bits.
+    // RT_COLORS_MB (default 8192) and the queue index within 32 bits.
     const long long nSlots = (long long)a.n_local_tiles * 64;
-    size_t budget = (size_t)std::max(16, envInt("RT_COLORS_MB", 4096)) << 20;
+    size_t budget = (size_t)std::max(16, envInt("RT_COLORS_MB", 8192)) << 20;
     if (fixed) {
         if ((size_t)nSlots > fixed->colors_cap)
             return fail(RT_ERR_LIMIT, "rt_render_noalloc: this context's share of the frame (" + std::to_string(nSlots) +
@@ -276,7 +276,8 @@ int launch(rt_context* ctx, rt::RenderArgs& a, bool count, const Workspace* fixe
     // Two passes (primaryPass, then the loop over its path records) for scenes whose tables are in LDS: the camera
     // rays of a tile are walked together, a full wave at a time, and the loop's SHADE and NEWPATH become one phase
     // (bench workload 18.7 ms against 19.95 for the single pass).  Costs 48 bytes of records per pixel sample of a
-    // launch (RT_RECORDS_MB, default 6400, bounds them).  Never for the fixed-scratch entry point or with the
+    // launch (RT_RECORDS_MB, default 25600, bounds them: four 1080p x 64 spp launches' worth; a 4K frame of 1024 spp
+    // takes 1,160 ms in launches of 64 spp and 1,218 ms in launches of 16).  Never for the fixed-scratch entry point or with the
     // reference-order walk forced.  A second kernel costs a start-up and a tail of its own (a path of 50 bounces takes
     // 0.3-0.4 ms whatever else the GPU does), so small launches stay with the single pass: 1080p x 16 spp 5.55 against
     // 5.73 ms, 1200x675 x 10 spp 2.05 against 2.41; the lines cross at about 45 M samples.  RT_TWO_PASS=1 / 0: always /
@@ -286,31 +287,40 @@ int launch(rt_context* ctx, rt::RenderArgs& a, bool count, const Workspace* fixe
     const bool twoPass = !fixed && ctx->use_lds && !a.sc.force_ref && a.max_depth >= 1 && twoPassKnob != 0 &&
                          (twoPassKnob > 0 || nSlots * (long long)a.n_samples >= kTwoPassMinSamples);
     constexpr size_t kRecordBytes = 48;
-    if (twoPass) budget = std::min(budget, ((size_t)std::max(16, envInt("RT_RECORDS_MB", 6400)) << 20) / kRecordBytes * sizeof(rt::Radiance));
+    if (twoPass) budget = std::min(budget, ((size_t)std::max(16, envInt("RT_RECORDS_MB", 25600)) << 20) / kRecordBytes * sizeof(rt::Radiance));
     size_t maxSamples = std::max<size_t>(1, budget / ((size_t)nSlots * sizeof(rt::Radiance)));
     maxSamples = std::min<size_t>(maxSamples, (size_t)((1ll << 31) / nSlots));
     maxSamples = std::max<size_t>(1, std::min<size_t>(maxSamples, (size_t)a.n_samples));
     const int first = a.first_sample, total = a.n_samples;
-    for (int s0 = 0; s0 < total; s0 += (int)maxSamples) {
-        const int ns = std::min((int)maxSamples, total - s0);
-        const size_t need = (size_t)nSlots * (size_t)ns;
-        if (!fixed && need > ctx->colors_cap) {
+    // The buffers of the largest launch, allocated up front; when the device has not that much memory left the
+    // launches are halved until they fit.
+    while (!fixed) {
+        const size_t need = (size_t)nSlots * maxSamples;
+        hipError_t e = hipSuccess;
+        if (need > ctx->colors_cap) {
             HIP_TRY(hipStreamSynchronize(ctx->stream));
             if (ctx->colors) (void)hipFree(ctx->colors);
             ctx->colors = nullptr;
             ctx->colors_cap = 0;
-            HIP_TRY(hipMalloc((void**)&ctx->colors, need * sizeof(rt::Radiance)));
-            ctx->colors_cap = need;
+            e = hipMalloc((void**)&ctx->colors, need * sizeof(rt::Radiance));
+            if (e == hipSuccess) ctx->colors_cap = need;
         }
-        if (twoPass && need > ctx->records_cap) {
+        if (e == hipSuccess && twoPass && need > ctx->records_cap) {
             HIP_TRY(hipStreamSynchronize(ctx->stream));
             if (ctx->records) (void)hipFree(ctx->records);
             ctx->records = nullptr;
             ctx->records_cap = 0;
             // + one byte per chunk of 64 for the record counts, read a dword at a time
-            HIP_TRY(hipMalloc((void**)&ctx->records, need * kRecordBytes + need / 64 + 16));
-            ctx->records_cap = need;
+            e = hipMalloc((void**)&ctx->records, need * kRecordBytes + need / 64 + 16);
+            if (e == hipSuccess) ctx->records_cap = need;
         }
+        if (e == hipSuccess) break;
+        (void)hipGetLastError();
+        if (e != hipErrorOutOfMemory || maxSamples == 1) HIP_TRY(e);
+        maxSamples = (maxSamples + 1) / 2;
+    }
+    for (int s0 = 0; s0 < total; s0 += (int)maxSamples) {
+        const int ns = std::min((int)maxSamples, total - s0);
         a.first_sample = first + s0;
         a.n_samples = ns;
         a.colors = fixed ? fixed->colors : ctx->colors;
