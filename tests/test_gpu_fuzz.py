@@ -1,7 +1,7 @@
 """Randomised worlds through the GPU path and the oracle (a slice of profiles/fuzz_parity.py, which
 ran 60,000 worlds = 531 M rays without a differing bit): spheres of every material, loose triangles,
-meshes with and without smooth normals / PBR maps / normal maps / depth limits, coincident primitives,
-cameras inside and outside the world, ragged frame sizes.  Seed 61890 is kept by name: paths that bounce
+meshes with and without smooth normals / PBR maps / normal maps / depth limits -- baked, or in every fourth world
+held once and placed by transforms --, coincident primitives, cameras inside and outside the world, ragged frame sizes.  Seed 61890 is kept by name: paths that bounce
 inside a glass ground sphere reach the small spheres from 66 units away, where Sphere::Hit's discriminant
 (R/src/Core/Hittable.h:236-239) is so inaccurate that it reports hits for rays that pass a sphere at 1.5 radii
 -- which the search structure has to let through (a fixed padding did not)."""
