@@ -140,26 +140,6 @@ int devUpload(rt_context* ctx, const std::vector<T>& host, const T** out) {
     return devUploadRaw<T, T>(ctx, host.data(), host.size(), out);
 }
 
-// fn(first, last) over [0, n) in contiguous pieces on up to 16 threads (RT_BUILD_THREADS, as the host-side
-// builders); small ranges run on the caller's thread
-template <class F>
-void parallelRanges(size_t n, F fn) {
-    unsigned threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
-    if (const char* e = std::getenv("RT_BUILD_THREADS")) threads = (unsigned)std::max(1, std::atoi(e));
-    if (n < (1u << 16) || threads < 2) {
-        fn((size_t)0, n);
-        return;
-    }
-    const size_t piece = (n + threads - 1) / threads;
-    std::vector<std::thread> pool;
-    for (unsigned t = 1; t < threads; t++) {
-        const size_t a = std::min(n, t * piece), b = std::min(n, a + piece);
-        if (a < b) pool.emplace_back([=] { fn(a, b); });
-    }
-    fn((size_t)0, std::min(n, piece));
-    for (auto& th : pool) th.join();
-}
-
 // RT_HOST_TIMING=1: the phases of rt_upload_scene() on stderr (host preparation, copies, device build)
 struct PhaseClock {
     bool on = envInt("RT_HOST_TIMING", 0) != 0;
@@ -787,7 +767,7 @@ int rt_upload_scene(rt_context* ctx, rt_scene* s) {
     const size_t nTri = sc.triangles.size();
     std::unique_ptr<float4[]> triI(new float4[nTri * 3 + 1]), triS(new float4[nTri * 4 + 1]);
     std::unique_ptr<int[]> triMat(new int[nTri + 1]);
-    parallelRanges(nTri, [&](size_t first, size_t last) {
+    rt::parallelPieces(nTri, [&](size_t first, size_t last) {
       bool huge = false;
       for (size_t i = first; i < last; i++) {
         const rt::HostTriangle& t = sc.triangles[i];
@@ -811,7 +791,7 @@ int rt_upload_scene(rt_context* ctx, rt_scene* s) {
     std::vector<float4> triF;
     if (sc.normal_mapping) {
         triF.resize(sc.triangles.size() * 2);
-        parallelRanges(nTri, [&](size_t first, size_t last) {
+        rt::parallelPieces(nTri, [&](size_t first, size_t last) {
             for (size_t i = first; i < last; i++) {
                 const rt::HostTriangle& t = sc.triangles[i];
                 float tan[3], bit[3];
@@ -838,7 +818,7 @@ int rt_upload_scene(rt_context* ctx, rt_scene* s) {
         size_t n = (size_t)t.w * t.h, base = texels.size();
         if (base + n > (size_t)0x7FFFFFFF) return fail(RT_ERR_LIMIT, "texture pool beyond 2^31 texels");
         texels.resize(base + n);
-        parallelRanges(n, [&](size_t first, size_t last) {
+        rt::parallelPieces(n, [&](size_t first, size_t last) {
             for (size_t p = first; p < last; p++)
                 texels[base + p] = (uint32_t)t.rgb[3 * p] | ((uint32_t)t.rgb[3 * p + 1] << 8) | ((uint32_t)t.rgb[3 * p + 2] << 16);
         });
