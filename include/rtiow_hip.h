@@ -73,15 +73,16 @@ int rt_scene_add_texture_rgb8(rt_scene* s, int width, int height, const uint8_t*
  * map (R/vendor/stb_image/stb_image.h:1840-1861, called from R/src/Material/Texture.h:11), which
  * the kernels apply per channel when they sample.  Host only. */
 int rt_texture_lut256(float* out256);
-/* Texture(path) (R/src/Material/Texture.h:7-29): reads and decodes a baseline JPEG or a non-interlaced
- * PNG file with the library's own decoder -- whose bytes equal stbi_load()'s of the stb_image v2.27 the
+/* Texture(path) (R/src/Material/Texture.h:7-29): reads and decodes a JPEG (sequential or progressive) or a
+ * PNG (interlaced or not) file with the library's own decoder -- whose bytes equal stbi_load()'s of the stb_image v2.27 the
  * reference vendors -- and keeps three channels per texel (grey replicated, alpha dropped; the
  * reference copies the first three floats of every texel whatever the file's channel count,
  * Texture.h:17-22, which is only meaningful for 3-channel files).  Returns the texture index. */
 int rt_scene_add_texture_file(rt_scene* s, const char* path);
 /* The decoder by itself: a JPEG / PNG file held in memory -> width, height, channel count as stored
  * (1, 2, 3 or 4) and, when `pixels` is not NULL, width * height * channels bytes, top row first.
- * Call once with pixels = NULL for the sizes.  Progressive JPEG and interlaced PNG are refused. */
+ * Call once with pixels = NULL for the sizes.  Arithmetic-coded, lossless, 12-bit and four-component (CMYK)
+ * JPEG files are refused. */
 int rt_image_decode(const uint8_t* file_bytes, size_t n_bytes, int* width, int* height, int* channels, uint8_t* pixels,
                     size_t pixels_capacity);
 /* PBRMaterial(diffuse) + setRoughnessTexture + setNormalTexture (Material.h:119,162-163);

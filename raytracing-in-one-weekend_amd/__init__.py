@@ -344,7 +344,7 @@ def texture_lut():
 
 
 def image_decode(file_bytes):
-    """Decodes a baseline JPEG or non-interlaced PNG: HxWxC uint8, C as stored in the file."""
+    """Decodes a JPEG (sequential or progressive) or PNG (interlaced or not): HxWxC uint8, C as stored in the file."""
     buf = np.frombuffer(bytes(file_bytes), np.uint8)
     w, h, c = C.c_int(), C.c_int(), C.c_int()
     _check(lib.rt_image_decode(_p(buf), buf.size, C.byref(w), C.byref(h), C.byref(c), None, 0))

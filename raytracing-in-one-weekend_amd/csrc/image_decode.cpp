@@ -1,4 +1,5 @@
-// Baseline JPEG and PNG decoding for texture files: the part of stb_image (v2.27, the copy the
+// JPEG (sequential and progressive, Huffman-coded) and PNG (plain and Adam7-interlaced) decoding for texture files:
+// the part of stb_image (v2.27, the copy the
 // reference vendors) that Texture's constructor relies on (R/src/Material/Texture.h:11 calls
 // stbi_loadf).  Written from the file formats (ITU T.81, RFC 1950/1951, the PNG specification); where
 // a format leaves the arithmetic to the decoder -- the inverse DCT, chroma upsampling and the
@@ -45,6 +46,7 @@ struct Component {
     int x = 0, y = 0, w2 = 0, h2 = 0;  // size in samples, size of the padded plane
     int pred = 0;
     std::vector<uint8_t> plane;
+    std::vector<int16_t> coef;  // progressive files: the coefficients of every block of the padded plane, natural order
 };
 
 struct JpegReader {
@@ -255,7 +257,7 @@ bool decodeJpeg(const uint8_t* data, size_t n, Image* img, std::string* err) {
     Huffman dc[4], ac[4];
     Component comp[3];
     int nComp = 0, width = 0, height = 0, hMax = 1, vMax = 1, mcuX = 0, mcuY = 0, restart = 0;
-    bool jfif = false, haveFrame = false, sawScan = false;
+    bool jfif = false, haveFrame = false, sawScan = false, progressive = false;
     int adobeTransform = -1;
     auto be16 = [&](int* out) {
         int a, b;
@@ -283,10 +285,11 @@ bool decodeJpeg(const uint8_t* data, size_t n, Image* img, std::string* err) {
         if (!be16(&len) || len < 2 || rd.p + (len - 2) > rd.end) return fail("bad segment length");
         const uint8_t* seg = rd.p;
         const uint8_t* segEnd = rd.p + (len - 2);
-        if (m == 0xC2 || (m >= 0xC5 && m <= 0xCF && m != 0xC8 && m != 0xCC))
-            return fail("progressive, lossless and arithmetic-coded JPEG files are not supported (baseline only)");
-        if (m == 0xC0 || m == 0xC1) {
+        if (m == 0xC3 || (m >= 0xC5 && m <= 0xCF && m != 0xC8 && m != 0xCC))
+            return fail("lossless, hierarchical and arithmetic-coded JPEG files are not supported");
+        if (m == 0xC0 || m == 0xC1 || m == 0xC2) {
             if (haveFrame) return fail("two frame headers");
+            progressive = m == 0xC2;
             if (len < 8 || seg[0] != 8) return fail("only 8-bit samples are supported");
             height = (seg[1] << 8) | seg[2];
             width = (seg[3] << 8) | seg[4];
@@ -316,6 +319,7 @@ bool decodeJpeg(const uint8_t* data, size_t n, Image* img, std::string* err) {
                 c.w2 = mcuX * c.h * 8;
                 c.h2 = mcuY * c.v * 8;
                 c.plane.assign((size_t)c.w2 * c.h2, 0);
+                if (progressive) c.coef.assign((size_t)c.w2 * c.h2, 0);
             }
             haveFrame = true;
         } else if (m == 0xC4) {  // Huffman tables
@@ -373,11 +377,112 @@ bool decodeJpeg(const uint8_t* data, size_t n, Image* img, std::string* err) {
                 if (comp[which].td > 3 || comp[which].ta > 3) return fail("bad table selector");
                 order[i] = which;
             }
-            if (seg[1 + 2 * ns] != 0 || seg[2 + 2 * ns] != 63) return fail("not a sequential scan");
+            // spectral selection and successive approximation (T.81 annex G; stb_image.h:3074-3087)
+            const int specStart = seg[1 + 2 * ns], specEnd = seg[2 + 2 * ns], succHigh = seg[3 + 2 * ns] >> 4, succLow = seg[3 + 2 * ns] & 15;
+            if (progressive) {
+                if (specStart > 63 || specEnd > 63 || specStart > specEnd || succHigh > 13 || succLow > 13) return fail("bad scan header");
+                if (specStart == 0 && specEnd != 0) return fail("a scan with DC and AC coefficients in a progressive file");
+                if (specStart != 0 && ns != 1) return fail("an interleaved AC scan in a progressive file");
+            } else if (specStart != 0 || specEnd != 63 || succHigh != 0 || succLow != 0) {
+                return fail("not a sequential scan");
+            }
             rd.p = segEnd;
             rd.resetBits();
             for (int k = 0; k < nComp; k++) comp[k].pred = 0;
+            int eobRun = 0;
+            // One block of a progressive scan (T.81 G.1.2, G.2; stb_image.h:2185-2323): the DC coefficient's first
+            // scan or one more of its bits; a band of AC coefficients' first scan (with runs of blocks that end
+            // early), or one more bit of the band (new coefficients come in as +-1 << succLow between the
+            // correction bits of the ones that are already non-zero).
+            auto blockProgressive = [&](Component& c, int bx, int by) -> bool {
+                int16_t* d = &c.coef[((size_t)by * (c.w2 / 8) + (size_t)bx) * 64];
+                if (specStart == 0) {
+                    if (succHigh == 0) {
+                        const Huffman& hd = dc[c.td];
+                        if (!hd.present) return false;
+                        std::memset(d, 0, 64 * sizeof(int16_t));
+                        const int t = rd.decode(hd);
+                        if (t < 0 || t > 15) return false;
+                        c.pred += rd.receiveExtend(t);
+                        d[0] = (int16_t)(c.pred * (1 << succLow));
+                    } else if (rd.bit()) {
+                        d[0] = (int16_t)(d[0] + (int16_t)(1 << succLow));
+                    }
+                    return true;
+                }
+                const Huffman& ha = ac[c.ta];
+                if (!ha.present) return false;
+                if (succHigh == 0) {
+                    if (eobRun) {
+                        --eobRun;
+                        return true;
+                    }
+                    int k = specStart;
+                    do {
+                        const int rs = rd.decode(ha);
+                        if (rs < 0) return false;
+                        const int sBits = rs & 15, r = rs >> 4;
+                        if (sBits == 0) {
+                            if (r < 15) {
+                                eobRun = 1 << r;
+                                if (r) eobRun += rd.receive(r);
+                                --eobRun;
+                                break;
+                            }
+                            k += 16;
+                        } else {
+                            k += r;
+                            if (k > 63) return false;
+                            d[kZigzag[k++]] = (int16_t)(rd.receiveExtend(sBits) * (1 << succLow));
+                        }
+                    } while (k <= specEnd);
+                    return true;
+                }
+                const int16_t bit = (int16_t)(1 << succLow);
+                auto correct = [&](int16_t* q) {  // one more bit of a coefficient that is already non-zero
+                    if (rd.bit() && (*q & bit) == 0) *q = (int16_t)(*q > 0 ? *q + bit : *q - bit);
+                };
+                if (eobRun) {
+                    --eobRun;
+                    for (int k = specStart; k <= specEnd; k++) {
+                        int16_t* q = &d[kZigzag[k]];
+                        if (*q != 0) correct(q);
+                    }
+                    return true;
+                }
+                int k = specStart;
+                do {
+                    const int rs = rd.decode(ha);
+                    if (rs < 0) return false;
+                    int sVal = rs & 15, r = rs >> 4;
+                    if (sVal == 0) {
+                        if (r < 15) {
+                            eobRun = (1 << r) - 1;
+                            if (r) eobRun += rd.receive(r);
+                            r = 64;  // to the end of the band: only correction bits from here
+                        }
+                        // (r == 15: sixteen zero coefficients -- fifteen skipped, the sixteenth "written" as 0)
+                    } else {
+                        if (sVal != 1) return false;
+                        sVal = rd.bit() ? bit : -bit;
+                    }
+                    while (k <= specEnd) {
+                        int16_t* q = &d[kZigzag[k++]];
+                        if (*q != 0) {
+                            correct(q);
+                        } else {
+                            if (r == 0) {
+                                *q = (int16_t)sVal;
+                                break;
+                            }
+                            --r;
+                        }
+                    }
+                } while (k <= specEnd);
+                return true;
+            };
             auto block = [&](Component& c, int bx, int by) -> bool {
+                if (progressive) return blockProgressive(c, bx, by);
                 const Huffman &hd = dc[c.td], &ha = ac[c.ta];
                 if (!hd.present || !ha.present || !quantSet[c.tq]) return false;
                 const uint16_t* q = quant[c.tq];
@@ -415,6 +520,7 @@ bool decodeJpeg(const uint8_t* data, size_t n, Image* img, std::string* err) {
                     if (rd.marker >= 0xD0 && rd.marker <= 0xD7) {
                         rd.resetBits();
                         for (int k = 0; k < nComp; k++) comp[k].pred = 0;
+                        eobRun = 0;
                         todo = restart;
                     } else {
                         return false;  // no restart marker: the scan is over
@@ -449,6 +555,21 @@ bool decodeJpeg(const uint8_t* data, size_t n, Image* img, std::string* err) {
         rd.p = segEnd;
     }
     if (!haveFrame || !sawScan) return fail("no image data");
+    if (progressive) {
+        // every scan has been read: dequantise and transform the blocks that hold image samples (stb_image.h:3107-3125)
+        for (int i = 0; i < nComp; i++) {
+            Component& c = comp[i];
+            if (!quantSet[c.tq]) return fail("missing quantisation table");
+            const uint16_t* q = quant[c.tq];
+            const int bw = (c.x + 7) >> 3, bh = (c.y + 7) >> 3;
+            for (int by = 0; by < bh; by++)
+                for (int bx = 0; bx < bw; bx++) {
+                    int16_t* d = &c.coef[((size_t)by * (c.w2 / 8) + (size_t)bx) * 64];
+                    for (int k = 0; k < 64; k++) d[k] = (int16_t)(d[k] * q[k]);
+                    idctBlock(&c.plane[(size_t)by * 8 * c.w2 + (size_t)bx * 8], c.w2, d);
+                }
+        }
+    }
 
     // ---- upsample and colour-convert, row by row (stb_image.h:3858-3996)
     const int outN = nComp == 3 ? 3 : 1;
@@ -683,7 +804,7 @@ bool decodePng(const uint8_t* data, size_t n, Image* img, std::string* err) {
             if (depth != 1 && depth != 2 && depth != 4 && depth != 8 && depth != 16) return fail("bad bit depth");
             if (color != 0 && color != 2 && color != 3 && color != 4 && color != 6) return fail("bad colour type");
             if ((color == 3 && depth == 16) || ((color == 2 || color == 4 || color == 6) && depth < 8)) return fail("bad bit depth");
-            if (interlace) return fail("interlaced PNG files are not supported");
+            if (interlace > 1) return fail("unknown interlace method");
             header = true;
         } else if (!header) {
             return fail("first chunk is not IHDR");
@@ -700,53 +821,79 @@ bool decodePng(const uint8_t* data, size_t n, Image* img, std::string* err) {
         pos += 12 + (size_t)len;
     }
     const int fileCh = color == 0 ? 1 : (color == 2 ? 3 : (color == 3 ? 1 : (color == 4 ? 2 : 4)));
-    const size_t rowBytes = ((size_t)width * fileCh * depth + 7) / 8;
     const int bpp = std::max(1, fileCh * depth / 8);  // distance to the "previous pixel" of the filters
-    std::vector<uint8_t> raw;
-    if (!inflateZlib(idat, &raw, (rowBytes + 1) * (size_t)height, err)) return false;
-    if (raw.size() < (rowBytes + 1) * (size_t)height) return fail("not enough image data");
-    // ---- undo the row filters (PNG specification, section 9)
-    std::vector<uint8_t> pix(rowBytes * (size_t)height);
-    for (int y = 0; y < height; y++) {
-        const uint8_t* src = &raw[(rowBytes + 1) * (size_t)y];
-        uint8_t* cur = &pix[rowBytes * (size_t)y];
-        const uint8_t* up = y ? cur - rowBytes : nullptr;
-        const int f = *src++;
-        if (f > 4) return fail("bad filter type");
-        for (size_t i = 0; i < rowBytes; i++) {
-            const int a = i >= (size_t)bpp ? cur[i - bpp] : 0, b = up ? up[i] : 0, c = (up && i >= (size_t)bpp) ? up[i - bpp] : 0;
-            int pred = 0;
-            if (f == 1) pred = a;
-            else if (f == 2) pred = b;
-            else if (f == 3) pred = (a + b) >> 1;
-            else if (f == 4) {
-                const int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c);
-                pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
-            }
-            cur[i] = (uint8_t)(src[i] + pred);
+    auto rowBytesOf = [&](int w) { return ((size_t)w * fileCh * depth + 7) / 8; };
+    // The image data is one filtered image, or with Adam7 interlacing seven of them one after the other: pass p
+    // holds the pixels (xorig + i * xspc, yorig + j * yspc) (PNG specification, section 8.2; stb_image.h:4740-4772).
+    struct Pass {
+        int x0, y0, dx, dy, w, h;
+    };
+    std::vector<Pass> passes;
+    if (interlace) {
+        static const int xorig[7] = {0, 4, 0, 2, 0, 1, 0}, yorig[7] = {0, 0, 4, 0, 2, 0, 1};
+        static const int xspc[7] = {8, 8, 4, 4, 2, 2, 1}, yspc[7] = {8, 8, 8, 4, 4, 2, 2};
+        for (int p = 0; p < 7; p++) {
+            const int w = (width - xorig[p] + xspc[p] - 1) / xspc[p], h = (height - yorig[p] + yspc[p] - 1) / yspc[p];
+            if (w > 0 && h > 0) passes.push_back({xorig[p], yorig[p], xspc[p], yspc[p], w, h});
         }
+    } else {
+        passes.push_back({0, 0, 1, 1, width, height});
     }
-    // ---- to 8-bit samples: low bit depths are unpacked (grey levels scaled to 0..255, palette
-    // indices kept), 16-bit samples keep their high byte (stb_image.h:4774-4801, 1208-1222)
+    size_t expect = 0;
+    for (const Pass& ps : passes) expect += (rowBytesOf(ps.w) + 1) * (size_t)ps.h;
+    std::vector<uint8_t> raw;
+    if (!inflateZlib(idat, &raw, expect, err)) return false;
+    if (raw.size() < expect) return fail("not enough image data");
     const size_t nSamples = (size_t)width * height * fileCh;
     std::vector<uint8_t> s8(nSamples);
     std::vector<uint16_t> s16;
-    if (depth == 8) {
-        s8 = pix;
-    } else if (depth == 16) {
-        s16.resize(nSamples);
-        for (size_t i = 0; i < nSamples; i++) {
-            s16[i] = (uint16_t)((pix[2 * i] << 8) | pix[2 * i + 1]);
-            s8[i] = pix[2 * i];
+    if (depth == 16) s16.resize(nSamples);
+    size_t at = 0;
+    std::vector<uint8_t> pix;
+    for (const Pass& ps : passes) {
+        const size_t rowBytes = rowBytesOf(ps.w);
+        // ---- undo the row filters (PNG specification, section 9)
+        pix.assign(rowBytes * (size_t)ps.h, 0);
+        for (int y = 0; y < ps.h; y++) {
+            const uint8_t* src = &raw[at + (rowBytes + 1) * (size_t)y];
+            uint8_t* cur = &pix[rowBytes * (size_t)y];
+            const uint8_t* up = y ? cur - rowBytes : nullptr;
+            const int f = *src++;
+            if (f > 4) return fail("bad filter type");
+            for (size_t i = 0; i < rowBytes; i++) {
+                const int a = i >= (size_t)bpp ? cur[i - bpp] : 0, b = up ? up[i] : 0, c = (up && i >= (size_t)bpp) ? up[i - bpp] : 0;
+                int pred = 0;
+                if (f == 1) pred = a;
+                else if (f == 2) pred = b;
+                else if (f == 3) pred = (a + b) >> 1;
+                else if (f == 4) {
+                    const int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c);
+                    pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+                }
+                cur[i] = (uint8_t)(src[i] + pred);
+            }
         }
-    } else {
-        const int scale = color == 0 ? (depth == 1 ? 0xff : (depth == 2 ? 0x55 : 0x11)) : 1;
-        const size_t perRow = (size_t)width * fileCh;
-        for (int y = 0; y < height; y++)
-            for (size_t i = 0; i < perRow; i++) {
-                const size_t bit = i * depth;
-                const int v = (pix[rowBytes * (size_t)y + bit / 8] >> (8 - depth - (int)(bit % 8))) & ((1 << depth) - 1);
-                s8[perRow * (size_t)y + i] = (uint8_t)(v * scale);
+        at += (rowBytes + 1) * (size_t)ps.h;
+        // ---- to 8-bit samples at the pass's pixels: low bit depths are unpacked (grey levels scaled to 0..255,
+        // palette indices kept), 16-bit samples keep their high byte (stb_image.h:4774-4801, 1208-1222)
+        const int scale = (depth < 8 && color == 0) ? (depth == 1 ? 0xff : (depth == 2 ? 0x55 : 0x11)) : 1;
+        for (int y = 0; y < ps.h; y++)
+            for (int x = 0; x < ps.w; x++) {
+                const size_t dst = ((size_t)(ps.y0 + y * ps.dy) * width + (size_t)(ps.x0 + x * ps.dx)) * fileCh;
+                for (int k = 0; k < fileCh; k++) {
+                    const size_t i = (size_t)x * fileCh + k;
+                    const uint8_t* row = &pix[rowBytes * (size_t)y];
+                    if (depth == 8) {
+                        s8[dst + k] = row[i];
+                    } else if (depth == 16) {
+                        s16[dst + k] = (uint16_t)((row[2 * i] << 8) | row[2 * i + 1]);
+                        s8[dst + k] = row[2 * i];
+                    } else {
+                        const size_t bit = i * depth;
+                        const int v = (row[bit / 8] >> (8 - depth - (int)(bit % 8))) & ((1 << depth) - 1);
+                        s8[dst + k] = (uint8_t)(v * scale);
+                    }
+                }
             }
     }
     // ---- palette expansion / colour-key transparency (stb_image.h:4803-4880, 5050-5100)

@@ -1,4 +1,4 @@
-// Baseline JPEG and PNG decoding for texture files (host code; see image_decode.cpp).
+// JPEG and PNG decoding for texture files (host code; see image_decode.cpp).
 #pragma once
 #include <algorithm>
 #include <cstdint>
@@ -14,7 +14,8 @@ struct Image {
     std::vector<uint8_t> px;  // tightly packed, row 0 = top row of the picture
 };
 
-// Decodes a baseline (sequential, Huffman, 8-bit) JPEG or a non-interlaced PNG held in memory.
+// Decodes a Huffman-coded 8-bit JPEG (sequential or progressive; 1 or 3 components) or a PNG (any colour type and bit
+// depth, interlaced or not) held in memory.
 // The bytes equal what stbi_load(..., req_comp = 0) of stb_image v2.27 returns for the same file.
 bool decodeImage(const uint8_t* data, size_t n, Image* out, std::string* err);
 // Three channels per texel: grey replicated, alpha dropped.

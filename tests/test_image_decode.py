@@ -24,11 +24,6 @@ NAMES = sorted(k for k in EXPECTED.files if not k.endswith(":channels"))
 def test_decoder_equals_stb_image(rt, name):
     blob = open(os.path.join(IMG, name), "rb").read()
     want = EXPECTED[name]
-    if "progressive" in name:
-        with pytest.raises(rt.RtError) as e:      # refused loudly, never mis-decoded
-            rt.image_decode(blob)
-        assert "progressive" in str(e.value)
-        return
     got = rt.image_decode(blob)
     assert got.shape == want.shape, (got.shape, want.shape)
     assert got.shape[2] == int(EXPECTED[name + ":channels"])
@@ -38,7 +33,9 @@ def test_decoder_equals_stb_image(rt, name):
 def test_every_decoder_path_has_a_fixture():
     kinds = " ".join(NAMES)
     for needle in ("rgb420", "rgb422", "rgb444", "grey_", "restart", "odd", "optimised", "rgba8", "palette", "bilevel",
-                   "rgb16", "greyalpha", "uncompressed"):
+                   "rgb16", "greyalpha", "uncompressed", "progressive_420", "progressive_422", "progressive_444",
+                   "progressive_grey", "progressive_420_restart", "interlaced_rgb8", "interlaced_grey1", "interlaced_palette4",
+                   "interlaced_rgb16", "interlaced_rgba8"):
         assert needle in kinds, needle
 
 
@@ -70,8 +67,18 @@ def test_texture_file_entry_point(rt, tmp_path):
     assert (t, t2) == (0, 1) and s.flatten().n_textures == 2
     with pytest.raises(rt.RtError):
         s.add_texture_file(str(tmp_path / "missing.jpg"))
-    with pytest.raises(rt.RtError):
-        s.add_texture_file(os.path.join(IMG, "rgb_progressive_32x32.jpg"))
+    t3 = s.add_texture_file(os.path.join(IMG, "rgb_progressive_32x32.jpg"))
+    t4 = s.add_texture_file(os.path.join(IMG, "interlaced_rgb8_29x13.png"))
+    assert (t3, t4) == (2, 3)
+    # a frame header that announces arithmetic coding (SOF9 in place of SOF0): refused loudly, never mis-decoded
+    blob = bytearray(open(os.path.join(IMG, "rgb420_64x48.jpg"), "rb").read())
+    at = blob.index(b"\xff\xc0")
+    blob[at + 1] = 0xC9
+    bad = tmp_path / "arithmetic.jpg"
+    bad.write_bytes(bytes(blob))
+    with pytest.raises(rt.RtError) as e:
+        s.add_texture_file(str(bad))
+    assert "arithmetic" in str(e.value)
 
 
 @pytest.mark.skipif(not os.path.isdir(REF_TEX), reason="the reference's assets exist in the build container only")
