@@ -81,8 +81,8 @@ int rt_texture_lut256(float* out256);
 int rt_scene_add_texture_file(rt_scene* s, const char* path);
 /* The decoder by itself: a JPEG / PNG file held in memory -> width, height, channel count as stored
  * (1, 2, 3 or 4) and, when `pixels` is not NULL, width * height * channels bytes, top row first.
- * Call once with pixels = NULL for the sizes.  Arithmetic-coded, lossless, 12-bit and four-component (CMYK)
- * JPEG files are refused. */
+ * Call once with pixels = NULL for the sizes.  Arithmetic-coded, lossless and 12-bit JPEG files are refused
+ * (as stb_image refuses them); four-component files come out as three channels, as from stb_image. */
 int rt_image_decode(const uint8_t* file_bytes, size_t n_bytes, int* width, int* height, int* channels, uint8_t* pixels,
                     size_t pixels_capacity);
 /* PBRMaterial(diffuse) + setRoughnessTexture + setNormalTexture (Material.h:119,162-163);

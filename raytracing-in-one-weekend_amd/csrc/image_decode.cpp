@@ -255,7 +255,7 @@ bool decodeJpeg(const uint8_t* data, size_t n, Image* img, std::string* err) {
     uint16_t quant[4][64];
     bool quantSet[4] = {false, false, false, false};
     Huffman dc[4], ac[4];
-    Component comp[3];
+    Component comp[4];
     int nComp = 0, width = 0, height = 0, hMax = 1, vMax = 1, mcuX = 0, mcuY = 0, restart = 0;
     bool jfif = false, haveFrame = false, sawScan = false, progressive = false;
     int adobeTransform = -1;
@@ -295,7 +295,7 @@ bool decodeJpeg(const uint8_t* data, size_t n, Image* img, std::string* err) {
             width = (seg[3] << 8) | seg[4];
             nComp = seg[5];
             if (width <= 0 || height <= 0) return fail("empty image");
-            if (nComp != 1 && nComp != 3) return fail("only 1- and 3-component files are supported");
+            if (nComp != 1 && nComp != 3 && nComp != 4) return fail("bad component count");
             if (len != 8 + 3 * nComp) return fail("bad frame header");
             for (int i = 0; i < nComp; i++) {
                 comp[i].id = seg[6 + 3 * i];
@@ -366,7 +366,7 @@ bool decodeJpeg(const uint8_t* data, size_t n, Image* img, std::string* err) {
             if (len < 3) return fail("bad scan header");  // seg[0] lies inside the segment from here on
             const int ns = seg[0];
             if (ns < 1 || ns > nComp || len != 6 + 2 * ns) return fail("bad scan header");
-            int order[3];
+            int order[4];
             for (int i = 0; i < ns; i++) {
                 int which = -1;
                 for (int k = 0; k < nComp; k++)
@@ -572,7 +572,7 @@ bool decodeJpeg(const uint8_t* data, size_t n, Image* img, std::string* err) {
     }
 
     // ---- upsample and colour-convert, row by row (stb_image.h:3858-3996)
-    const int outN = nComp == 3 ? 3 : 1;
+    const int outN = nComp >= 3 ? 3 : 1;
     img->w = width;
     img->h = height;
     img->channels = outN;
@@ -583,7 +583,7 @@ bool decodeJpeg(const uint8_t* data, size_t n, Image* img, std::string* err) {
         int hs, vs, wLo, ystep, ypos;
         const uint8_t *line0, *line1;
         std::vector<uint8_t> buf;
-    } up[3];
+    } up[4];
     for (int k = 0; k < nComp; k++) {
         up[k].hs = hMax / comp[k].h;
         up[k].vs = vMax / comp[k].v;
@@ -594,7 +594,7 @@ bool decodeJpeg(const uint8_t* data, size_t n, Image* img, std::string* err) {
         up[k].buf.assign((size_t)width + 8, 0);
     }
     for (int j = 0; j < height; j++) {
-        const uint8_t* row[3] = {nullptr, nullptr, nullptr};
+        const uint8_t* row[4] = {nullptr, nullptr, nullptr, nullptr};
         for (int k = 0; k < nComp; k++) {
             Up& u = up[k];
             const bool bottom = u.ystep >= (u.vs >> 1);
@@ -608,6 +608,23 @@ bool decodeJpeg(const uint8_t* data, size_t n, Image* img, std::string* err) {
         uint8_t* out = &img->px[(size_t)j * width * outN];
         if (nComp == 1) {
             std::memcpy(out, row[0], (size_t)width);
+        } else if (nComp == 4) {
+            // four components (stb_image.h:3924-3947): CMYK as Adobe writes it (stored inverted: a product with K),
+            // YCCK (the first three through the YCbCr map, then inverted and multiplied with K), or -- without an
+            // Adobe marker that says which -- YCbCr with a fourth channel that is ignored
+            auto blinn = [](int x, int y) {  // x * y / 255, rounded (stb_image.h:3718-3722)
+                const unsigned t = (unsigned)(x * y + 128);
+                return (uint8_t)((t + (t >> 8)) >> 8);
+            };
+            if (adobeTransform == 0) {
+                for (int i = 0; i < width; i++)
+                    for (int k = 0; k < 3; k++) out[3 * i + k] = blinn(row[k][i], row[3][i]);
+            } else {
+                yccToRgb(out, row[0], row[1], row[2], width);
+                if (adobeTransform == 2)
+                    for (int i = 0; i < width; i++)
+                        for (int k = 0; k < 3; k++) out[3 * i + k] = blinn(255 - out[3 * i + k], row[3][i]);
+            }
         } else if (isRgb) {
             for (int i = 0; i < width; i++) {
                 out[3 * i] = row[0][i];

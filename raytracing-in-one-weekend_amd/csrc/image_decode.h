@@ -14,7 +14,7 @@ struct Image {
     std::vector<uint8_t> px;  // tightly packed, row 0 = top row of the picture
 };
 
-// Decodes a Huffman-coded 8-bit JPEG (sequential or progressive; 1 or 3 components) or a PNG (any colour type and bit
+// Decodes a Huffman-coded 8-bit JPEG (sequential or progressive; 1, 3 or 4 components) or a PNG (any colour type and bit
 // depth, interlaced or not) held in memory.
 // The bytes equal what stbi_load(..., req_comp = 0) of stb_image v2.27 returns for the same file.
 bool decodeImage(const uint8_t* data, size_t n, Image* out, std::string* err);

@@ -119,6 +119,18 @@ def synthetic_images():
     jpeg("progressive_420_restart_72x56", picture(72, 56, 3), quality=85, subsampling=2, progressive=True, restart_marker_blocks=2)
     jpeg("progressive_420_large_200x120", picture(200, 120, 3), quality=60, subsampling=2, progressive=True, optimize=True)
     jpeg("progressive_444_tiny_3x2", picture(3, 2, 3), quality=90, subsampling=0, progressive=True)
+    # four components, with the Adobe marker's colour-transform byte as written and set to each of its other values
+    # (0: CMYK, 2: YCCK, anything else: the fourth channel is ignored) -- stb_image.h:3924-3947
+    def cmyk(name, arr, **kw):
+        b = io.BytesIO()
+        Image.fromarray(arr, "CMYK").save(b, "JPEG", **kw)
+        blob = bytearray(b.getvalue())
+        at = blob.index(b"Adobe") + 11
+        for t in (0, 1, 2):
+            blob[at] = t
+            out[f"{name}_transform{t}.jpg"] = bytes(blob)
+    cmyk("cmyk_37x22", picture(37, 22, 4), quality=85)
+    cmyk("cmyk_progressive_420_40x31", picture(40, 31, 4), quality=70, progressive=True, subsampling=2)
     png("rgb8_31x17", Image.fromarray(picture(31, 17, 3)))
     png("rgba8_20x20", Image.fromarray(picture(20, 20, 4)))
     png("grey8_19x23", Image.fromarray(picture(19, 23, 1).squeeze()))

@@ -35,7 +35,7 @@ def test_every_decoder_path_has_a_fixture():
     for needle in ("rgb420", "rgb422", "rgb444", "grey_", "restart", "odd", "optimised", "rgba8", "palette", "bilevel",
                    "rgb16", "greyalpha", "uncompressed", "progressive_420", "progressive_422", "progressive_444",
                    "progressive_grey", "progressive_420_restart", "interlaced_rgb8", "interlaced_grey1", "interlaced_palette4",
-                   "interlaced_rgb16", "interlaced_rgba8"):
+                   "interlaced_rgb16", "interlaced_rgba8", "cmyk_37x22_transform0", "transform1", "transform2", "cmyk_progressive"):
         assert needle in kinds, needle
 
 
