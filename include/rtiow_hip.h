@@ -106,14 +106,16 @@ int rt_scene_add_box(rt_scene* s, const float* p0, const float* p1, int material
  * indices: 3 per triangle.  Returns the id of the mesh's first triangle. */
 int rt_scene_add_mesh(rt_scene* s, const float* model16, int n_vertices, const float* positions, const float* normals,
                       const float* uvs, int n_triangles, const uint32_t* indices, int material, int max_depth);
-/* Reads a glTF 2.0 file (+ external .bin) with one mesh primitive and adds it as above
+/* Reads a glTF 2.0 file (.gltf with its buffers in files or "data:" URIs, or a .glb container) with one mesh
+ * primitive and adds it as above
  * (the part of Assimp::Importer::ReadFile that R/src/Core/Mesh.cpp:10-12 relies on).
  * Texture images are not decoded here; bind them through `material`. */
 int rt_scene_add_mesh_gltf(rt_scene* s, const float* model16, const char* gltf_path, int material, int max_depth);
 
 /* world.add(make_shared<Mesh>(model, file)) for a glTF 2.0 file, textures included: the whole of
  * Mesh::Mesh (R/src/Core/Mesh.cpp:7-37) with the library's own glTF reader and image decoder in place of
- * the importer and stb_image.  Every triangle-list primitive of every mesh, in the order processNode
+ * the importer and stb_image (.gltf or .glb; buffers and images in files beside it, in "data:" URIs or in the
+ * container's binary chunk).  Every triangle-list primitive of every mesh, in the order processNode
  * visits them (Mesh.cpp:39-52; node transforms are not applied there, nor here), becomes part of ONE
  * triangle list with one mesh box and one BVHNode(triangles, 0, n, max_depth).
  *   material < 0, per_primitive_materials = 0: the reference's rule (Mesh.cpp:56-104): one PBRMaterial

@@ -696,8 +696,8 @@ int Scene::addMesh(const float* model16, int n_vertices, const float* positions,
     return first;
 }
 
-// glTF 2.0 reader (the job Assimp::Importer::ReadFile does for R/src/Core/Mesh.cpp:10-12): external
-// .bin buffers and image files, triangle-list primitives with float POSITION / NORMAL / TEXCOORD_0
+// glTF 2.0 reader (the job Assimp::Importer::ReadFile does for R/src/Core/Mesh.cpp:10-12): .gltf and .glb,
+// buffers and images in files, "data:" URIs or the container's binary chunk, triangle-list primitives with float POSITION / NORMAL / TEXCOORD_0
 // and u8 / u16 / u32 (or no) indices.  Meshes are visited the way Mesh::processNode walks the importer's
 // node tree -- a node's meshes, then its children, from the scene's root nodes -- and, like the
 // reference, node transforms are NOT applied (processNode never reads aiNode::mTransformation; only
@@ -719,11 +719,77 @@ struct GltfDoc {
         return arr && arr->t == JValue::ARR && i >= 0 && i < (int)arr->arr.size() ? &arr->arr[(size_t)i] : nullptr;
     }
 
+    // RFC 4648 base64 (the payload of a "data:" URI after its comma); false on a character outside the alphabet
+    static bool base64(const std::string& in, size_t from, std::string* out) {
+        uint32_t acc = 0;
+        int bits = 0;
+        out->clear();
+        out->reserve((in.size() - from) * 3 / 4);
+        for (size_t i = from; i < in.size(); i++) {
+            const char c = in[i];
+            int v;
+            if (c >= 'A' && c <= 'Z') v = c - 'A';
+            else if (c >= 'a' && c <= 'z') v = c - 'a' + 26;
+            else if (c >= '0' && c <= '9') v = c - '0' + 52;
+            else if (c == '+' || c == '-') v = 62;
+            else if (c == '/' || c == '_') v = 63;
+            else if (c == '=' || c == '\n' || c == '\r' || c == ' ') continue;
+            else return false;
+            acc = (acc << 6) | (uint32_t)v;
+            bits += 6;
+            if (bits >= 8) {
+                bits -= 8;
+                out->push_back((char)((acc >> bits) & 0xFF));
+            }
+        }
+        return true;
+    }
+    static bool dataUri(const std::string& uri, std::string* out) {
+        const size_t comma = uri.find(',');
+        return comma != std::string::npos && uri.find(";base64") < comma && base64(uri, comma + 1, out);
+    }
+
+    std::string glbBin;  // the binary chunk of a .glb container: buffer 0 when that buffer names no uri
+
     bool open(const char* path, std::string* err) {
         std::string text;
         if (!readFile(path, &text)) {
             *err = std::string("cannot read ") + path;
             return false;
+        }
+        // Binary container (glTF 2.0 specification, section 4.4): 12-byte header {"glTF", version, length}, then
+        // chunks {length, type, data}: the JSON first, optionally one binary chunk after it.
+        if (text.size() >= 12 && text.compare(0, 4, "glTF") == 0) {
+            auto u32 = [&](size_t at) {
+                return (uint32_t)(uint8_t)text[at] | ((uint32_t)(uint8_t)text[at + 1] << 8) | ((uint32_t)(uint8_t)text[at + 2] << 16) |
+                       ((uint32_t)(uint8_t)text[at + 3] << 24);
+            };
+            if (u32(4) != 2) {
+                *err = "unsupported .glb version";
+                return false;
+            }
+            std::string json;
+            size_t at = 12;
+            bool haveJson = false;
+            while (at + 8 <= text.size()) {
+                const size_t len = u32(at), type = u32(at + 4);
+                if (len > text.size() - at - 8) {
+                    *err = "truncated .glb chunk";
+                    return false;
+                }
+                if (type == 0x4E4F534Au && !haveJson) {
+                    json.assign(text, at + 8, len);
+                    haveJson = true;
+                } else if (type == 0x004E4942u && glbBin.empty()) {
+                    glbBin.assign(text, at + 8, len);
+                }
+                at += 8 + ((len + 3) & ~(size_t)3);
+            }
+            if (!haveJson) {
+                *err = ".glb file without a JSON chunk";
+                return false;
+            }
+            text.swap(json);
         }
         JParser jp(text);
         root = jp.parse();
@@ -750,8 +816,17 @@ struct GltfDoc {
         blobs.resize(buffers->arr.size());
         for (size_t i = 0; i < buffers->arr.size(); i++) {
             const JValue* uri = buffers->arr[i].get("uri");
-            if (!uri || uri->t != JValue::STR || uri->str.compare(0, 5, "data:") == 0 || !readFile(dir + "/" + uri->str, &blobs[i])) {
-                *err = "cannot read glTF buffer (external .bin files only)";
+            bool got;
+            if (!uri)
+                got = i == 0 && !glbBin.empty() && (blobs[0] = glbBin, true);  // the .glb's own binary chunk
+            else if (uri->t != JValue::STR)
+                got = false;
+            else if (uri->str.compare(0, 5, "data:") == 0)
+                got = dataUri(uri->str, &blobs[i]);
+            else
+                got = readFile(dir + "/" + uri->str, &blobs[i]);
+            if (!got) {
+                *err = "cannot read glTF buffer " + std::to_string(i);
                 return false;
             }
         }
@@ -821,9 +896,31 @@ struct GltfDoc {
         const JValue* holder = pbr ? material->get("pbrMetallicRoughness") : material;
         const JValue* ref = holder ? holder->get(slot) : nullptr;
         const JValue* tex = ref ? at(textures, asIndex(ref->get("index"))) : nullptr;
-        const JValue* image = tex ? at(images, asIndex(tex->get("source"))) : nullptr;
-        const JValue* uri = image ? image->get("uri") : nullptr;
-        return uri && uri->t == JValue::STR && uri->str.compare(0, 5, "data:") != 0 ? uri->str : "";
+        const int source = tex ? asIndex(tex->get("source")) : -1;
+        const JValue* image = at(images, source);
+        if (!image) return "";
+        const JValue* uri = image->get("uri");
+        if (uri && uri->t == JValue::STR && uri->str.compare(0, 5, "data:") != 0) return uri->str;
+        // an image held in the file itself (a "data:" URI, or a bufferView as .glb files have them) goes by its number
+        if ((uri && uri->t == JValue::STR) || image->get("bufferView")) return kEmbedded + std::to_string(source);
+        return "";
+    }
+    static constexpr const char* kEmbedded = "\x01image:";
+    // The encoded bytes (JPEG / PNG) of an image held in the file itself.
+    bool embeddedImage(const std::string& key, std::string* out) const {
+        const JValue* image = at(images, std::atoi(key.c_str() + std::strlen(kEmbedded)));
+        if (!image) return false;
+        const JValue* uri = image->get("uri");
+        if (uri && uri->t == JValue::STR) return dataUri(uri->str, out);
+        const JValue* v = at(views, asIndex(image->get("bufferView")));
+        if (!v) return false;
+        const JValue *buf = v->get("buffer"), *off = v->get("byteOffset"), *len = v->get("byteLength");
+        const double b = buf ? buf->num : 0.0, o = off ? off->num : 0.0, l = len ? len->num : -1.0;
+        if (!(b >= 0) || b >= (double)blobs.size() || !(o >= 0) || !(l >= 0) || o > 4e9 || l > 4e9) return false;
+        const std::string& blob = blobs[(size_t)b];
+        if ((size_t)o + (size_t)l > blob.size()) return false;
+        out->assign(blob, (size_t)o, (size_t)l);
+        return true;
     }
 };
 
@@ -835,10 +932,14 @@ int Scene::textureFromFile(const std::string& path, std::string* err) {
         *err = "cannot read " + path;
         return -1;
     }
+    return textureFromBytes(bytes, path, err);
+}
+
+int Scene::textureFromBytes(const std::string& bytes, const std::string& label, std::string* err) {
     Image img;
     std::string why;
     if (!decodeImage(reinterpret_cast<const uint8_t*>(bytes.data()), bytes.size(), &img, &why)) {
-        *err = path + ": " + why;
+        *err = label + ": " + why;
         return -1;
     }
     std::vector<uint8_t> rgb;
@@ -873,7 +974,17 @@ int Scene::addMeshGltf(const float* model16, const char* path, int material, int
         if (file.empty()) return -1;
         auto it = loaded.find(file);
         if (it != loaded.end()) return it->second;
-        const int t = textureFromFile(g.dir + "/" + file, err);
+        int t;
+        if (file.compare(0, std::strlen(GltfDoc::kEmbedded), GltfDoc::kEmbedded) == 0) {
+            std::string bytes;
+            if (!g.embeddedImage(file, &bytes)) {
+                *err = "cannot read image " + file.substr(std::strlen(GltfDoc::kEmbedded)) + " of the glTF file";
+                return -1;
+            }
+            t = textureFromBytes(bytes, "glTF image " + file.substr(std::strlen(GltfDoc::kEmbedded)), err);
+        } else {
+            t = textureFromFile(g.dir + "/" + file, err);
+        }
         if (t >= 0) loaded[file] = t;
         return t;
     };

@@ -186,6 +186,7 @@ public:
     int addMeshGltf(const float* model16, const char* path, int material, int max_depth, bool per_primitive,
                     bool first_primitive_only, std::string* err);
     int textureFromFile(const std::string& path, std::string* err);
+    int textureFromBytes(const std::string& bytes, const std::string& label, std::string* err);
     // Ingestion of a tree the caller has already built (no random numbers are drawn): objects added
     // between beginGroup() and endGroup() become the children, in order, of one composite.
     // boxed = true: the caller's box is tested first, then the children are scanned with the running
