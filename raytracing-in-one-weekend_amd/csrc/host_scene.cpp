@@ -697,9 +697,9 @@ int Scene::addMesh(const float* model16, int n_vertices, const float* positions,
 }
 
 // glTF 2.0 reader (the job Assimp::Importer::ReadFile does for R/src/Core/Mesh.cpp:10-12): .gltf and .glb,
-// buffers and images in files, "data:" URIs or the container's binary chunk, triangle-list primitives with float POSITION / NORMAL / TEXCOORD_0
-// and u8 / u16 / u32 (or no) indices.  Meshes are visited the way Mesh::processNode walks the importer's
-// node tree -- a node's meshes, then its children, from the scene's root nodes -- and, like the
+// buffers and images in files, "data:" URIs or the container's binary chunk; triangle lists, strips and fans with
+// float POSITION / NORMAL, float or normalised u8 / u16 TEXCOORD_0, and u8 / u16 / u32 (or no) indices.  Meshes are
+// visited the way Mesh::processNode walks the importer's node tree -- a node's meshes, then its children, from the scene's root nodes -- and, like the
 // reference, node transforms are NOT applied (processNode never reads aiNode::mTransformation; only
 // the caller's model matrix is).  The V texture coordinate is flipped (1 - v), which is what the
 // importer used by the reference hands to Mesh.cpp:125-133 for glTF files.
@@ -1004,9 +1004,10 @@ int Scene::addMeshGltf(const float* model16, const char* path, int material, int
                 *err = "primitive needs POSITION";
                 return -1;
             }
-            const JValue* mode = prim.get("mode");
-            if (mode && GltfDoc::asIndex(mode) != 4) {
-                *err = "only triangle-list primitives (mode 4) are supported";
+            // triangle lists, strips and fans; points and lines have no surface to hit
+            const int mode = prim.get("mode") ? GltfDoc::asIndex(prim.get("mode")) : 4;
+            if (mode < 4 || mode > 6) {
+                *err = "only triangle primitives (modes 4, 5, 6) are supported";
                 return -1;
             }
             GltfDoc::View vp, vn, vt, vi;
@@ -1016,8 +1017,17 @@ int Scene::addMeshGltf(const float* model16, const char* path, int material, int
             }
             // optional attributes: absent is fine, present but unreadable is an error
             const bool hasN = attrs->get("NORMAL") != nullptr, hasT = attrs->get("TEXCOORD_0") != nullptr;
+            // texture coordinates: float, or unsigned bytes / shorts that stand for value / 255 and value / 65535
+            // (glTF 2.0 specification, section 3.7.2.1)
+            int uvComp = 5126;
+            if (hasT) {
+                const JValue* acc = GltfDoc::at(g.accessors, GltfDoc::asIndex(attrs->get("TEXCOORD_0")));
+                const JValue* ct = acc ? acc->get("componentType") : nullptr;
+                uvComp = ct && ct->t == JValue::NUM ? (int)ct->num : 0;
+            }
+            const size_t uvSize = uvComp == 5126 ? 4 : (uvComp == 5123 ? 2 : (uvComp == 5121 ? 1 : 0));
             if ((hasN && !(g.view(GltfDoc::asIndex(attrs->get("NORMAL")), 3, 4, &vn) && vn.comp == 5126 && vn.count == vp.count)) ||
-                (hasT && !(g.view(GltfDoc::asIndex(attrs->get("TEXCOORD_0")), 2, 4, &vt) && vt.comp == 5126 && vt.count == vp.count))) {
+                (hasT && !(uvSize && g.view(GltfDoc::asIndex(attrs->get("TEXCOORD_0")), 2, uvSize, &vt) && vt.count == vp.count))) {
                 *err = "bad NORMAL / TEXCOORD_0 accessor";
                 return -1;
             }
@@ -1035,7 +1045,18 @@ int Scene::addMeshGltf(const float* model16, const char* path, int material, int
             if (hasT)
                 for (size_t i = 0; i < nv; i++) {
                     float uvv[2];
-                    std::memcpy(uvv, vt.data + i * vt.stride, 8);
+                    const char* src = vt.data + i * vt.stride;
+                    if (uvComp == 5126) {
+                        std::memcpy(uvv, src, 8);
+                    } else if (uvComp == 5123) {
+                        uint16_t q[2];
+                        std::memcpy(q, src, 4);
+                        uvv[0] = (float)q[0] / 65535.0f;
+                        uvv[1] = (float)q[1] / 65535.0f;
+                    } else {
+                        uvv[0] = (float)(uint8_t)src[0] / 255.0f;
+                        uvv[1] = (float)(uint8_t)src[1] / 255.0f;
+                    }
                     T[2 * (base + i)] = uvv[0];
                     T[2 * (base + i) + 1] = 1.0f - uvv[1];
                 }
@@ -1044,6 +1065,8 @@ int Scene::addMeshGltf(const float* model16, const char* path, int material, int
             allN = allN && hasN;
             allT = allT && hasT;
             const size_t firstIndex = I.size();
+            std::vector<uint32_t> run;  // strips and fans: the primitive's vertex sequence, made into triangles below
+            std::vector<uint32_t>& I0 = mode == 4 ? I : run;
             if (prim.get("indices")) {
                 const int idxAcc = GltfDoc::asIndex(prim.get("indices"));
                 const JValue* acc = GltfDoc::at(g.accessors, idxAcc);
@@ -1061,10 +1084,24 @@ int Scene::addMeshGltf(const float* model16, const char* path, int material, int
                         *err = "index out of range in glTF mesh";
                         return -1;
                     }
-                    I.push_back((uint32_t)base + v);
+                    I0.push_back((uint32_t)base + v);
                 }
             } else {
-                for (size_t i = 0; i < nv; i++) I.push_back((uint32_t)(base + i));
+                for (size_t i = 0; i < nv; i++) I0.push_back((uint32_t)(base + i));
+            }
+            // Strip: triangle i is (i, i+1, i+2), with the first two swapped for odd i so that all wind the same way;
+            // fan: (0, i+1, i+2) -- the orders the importer the reference uses gives its faces (an assumption, like
+            // everything about that importer: it is not part of the reference tree).
+            for (size_t i = 0; mode != 4 && i + 2 < run.size(); i++) {
+                if (mode == 5) {
+                    I.push_back(run[i + (i & 1)]);
+                    I.push_back(run[i + 1 - (i & 1)]);
+                    I.push_back(run[i + 2]);
+                } else {
+                    I.push_back(run[0]);
+                    I.push_back(run[i + 1]);
+                    I.push_back(run[i + 2]);
+                }
             }
             const size_t nTri = (I.size() - firstIndex) / 3;
             I.resize(firstIndex + nTri * 3);

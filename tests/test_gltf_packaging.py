@@ -118,3 +118,64 @@ def test_three_packagings_give_one_picture(rt, scenes, gpu_ctx, tmp_path):
     assert images[0][..., :3].max() > 0
     assert np.array_equal(images[0].view(np.uint32), images[1].view(np.uint32))
     assert np.array_equal(images[0].view(np.uint32), images[2].view(np.uint32))
+
+
+def write_gltf(path, positions, uvs, indices, mode=None, uv_type=np.float32):
+    """One untextured primitive: positions (float), uvs of the given component type, u16 indices (or none)."""
+    parts = [positions.astype(np.float32).tobytes(), uvs.astype(uv_type).tobytes()]
+    if indices is not None:
+        parts.append(np.asarray(indices, np.uint16).tobytes())
+    offsets, blob = [], b""
+    for p in parts:
+        offsets.append(len(blob))
+        blob += p + b"\0" * (-len(p) % 4)
+    ct = {np.float32: 5126, np.uint16: 5123, np.uint8: 5121}[uv_type]
+    prim = {"attributes": {"POSITION": 0, "TEXCOORD_0": 1}}
+    acc = [{"bufferView": 0, "componentType": 5126, "count": len(positions), "type": "VEC3"},
+           {"bufferView": 1, "componentType": ct, "count": len(uvs), "type": "VEC2", "normalized": ct != 5126}]
+    if indices is not None:
+        prim["indices"] = 2
+        acc.append({"bufferView": 2, "componentType": 5123, "count": len(indices), "type": "SCALAR"})
+    if mode is not None:
+        prim["mode"] = mode
+    doc = {"asset": {"version": "2.0"}, "meshes": [{"primitives": [prim]}], "accessors": acc,
+           "bufferViews": [{"buffer": 0, "byteOffset": o, "byteLength": len(p)} for o, p in zip(offsets, parts)],
+           "buffers": [{"uri": "data:application/octet-stream;base64," + base64.b64encode(blob).decode(), "byteLength": len(blob)}]}
+    path.write_text(json.dumps(doc))
+    return str(path)
+
+
+def triangles_of(rt, path):
+    s = rt.Scene()
+    s.add_mesh_file(rt.IDENTITY, path, max_depth=4, material=s.add_material(0, (0.5, 0.5, 0.5)))
+    d = s.get_flat()
+    return d["tri_pos"].view(np.uint32), d["tri_uv"].view(np.uint32)
+
+
+def test_strips_fans_and_normalised_texture_coordinates(rt, tmp_path):
+    rs = np.random.RandomState(11)
+    pos = rs.rand(7, 3).astype(np.float32)
+    uv16 = rs.randint(0, 65536, (7, 2)).astype(np.uint16)
+    uv = uv16.astype(np.float32) / np.float32(65535.0)
+    seq = [3, 0, 5, 1, 6, 2, 4]
+    strip = [[seq[i + (i & 1)], seq[i + 1 - (i & 1)], seq[i + 2]] for i in range(5)]
+    fan = [[seq[0], seq[i + 1], seq[i + 2]] for i in range(5)]
+    for mode, want in ((5, strip), (6, fan)):
+        a = triangles_of(rt, write_gltf(tmp_path / f"mode{mode}.gltf", pos, uv, seq, mode=mode))
+        b = triangles_of(rt, write_gltf(tmp_path / f"list{mode}.gltf", pos, uv, np.array(want).reshape(-1)))
+        assert a[0].shape[0] == 5 and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    # without indices the vertices themselves are the sequence
+    a = triangles_of(rt, write_gltf(tmp_path / "strip_plain.gltf", pos, uv, None, mode=5))
+    b = triangles_of(rt, write_gltf(tmp_path / "strip_plain_list.gltf", pos, uv,
+                                    np.array([[i + (i & 1), i + 1 - (i & 1), i + 2] for i in range(5)]).reshape(-1)))
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    # unsigned short / byte texture coordinates stand for value / 65535 and value / 255
+    f = triangles_of(rt, write_gltf(tmp_path / "uv_float.gltf", pos, uv, seq[:6]))
+    q = triangles_of(rt, write_gltf(tmp_path / "uv_u16.gltf", pos, uv16, seq[:6], uv_type=np.uint16))
+    assert np.array_equal(f[0], q[0]) and np.array_equal(f[1], q[1])
+    uv8 = rs.randint(0, 256, (7, 2)).astype(np.uint8)
+    f = triangles_of(rt, write_gltf(tmp_path / "uv_float8.gltf", pos, uv8.astype(np.float32) / np.float32(255.0), seq[:6]))
+    q = triangles_of(rt, write_gltf(tmp_path / "uv_u8.gltf", pos, uv8, seq[:6], uv_type=np.uint8))
+    assert np.array_equal(f[1], q[1])
+    with pytest.raises(rt.RtError):      # lines have no surface
+        triangles_of(rt, write_gltf(tmp_path / "lines.gltf", pos, uv, seq, mode=1))
