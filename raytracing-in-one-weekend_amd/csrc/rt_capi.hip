@@ -266,6 +266,8 @@ int launch(rt_context* ctx, rt::RenderArgs& a, bool count, const Workspace* fixe
     const int twoPassKnob = envInt("RT_TWO_PASS", -1);
     const bool twoPass = !fixed && ctx->use_lds && !a.sc.force_ref && a.max_depth >= 1 && twoPassKnob != 0 &&
                          (twoPassKnob > 0 || nSlots * (long long)a.n_samples >= kTwoPassMinSamples);
+    // the loop over path records ends its box bursts a little earlier than the single-pass loop (18.71 against 18.80 ms)
+    if (twoPass && !std::getenv("RT_BOX_KEEP")) a.knob[0] = 16;
     constexpr size_t kRecordBytes = 48;
     if (twoPass) budget = std::min(budget, ((size_t)std::max(16, envInt("RT_RECORDS_MB", 25600)) << 20) / kRecordBytes * sizeof(rt::Radiance));
     size_t maxSamples = std::max<size_t>(1, budget / ((size_t)nSlots * sizeof(rt::Radiance)));
