@@ -344,3 +344,38 @@ def test_group_calls_must_balance(rt):
         s.wrap_bvh()
     s.end_group()
     assert s.flatten().n_spheres == 1
+
+
+def test_large_mesh_is_taken_in_by_several_threads_as_by_one(rt, orc, scenes, monkeypatch):
+    """From 65,536 faces on, the faces of a mesh (transform, normal matrix, mesh box) and the boxes of its triangles
+    are prepared in pieces on the builders' threads, and so are the padded boxes of the search structure: the
+    arrays must not depend on the number of threads, and must still be the oracle's."""
+    mesh = scenes.lathe_mesh(300, 120, seed=4)          # 72,000 triangles with smooth normals and uvs
+    assert mesh["indices"].shape[0] >= 65536
+
+    def build(s):
+        m = s.add_material(0, (0.5, 0.5, 0.5))
+        s.add_mesh(scenes.VASE_MODEL, mesh["positions"], mesh["indices"], m, normals=mesh["normals"], uvs=mesh["uvs"], max_depth=-1)
+
+    monkeypatch.setenv("RT_BUILD_THREADS", "8")
+    a, b = build_both(rt, orc, build)
+    flat = a.get_flat()
+    ea, ra = a.search_structure()
+    monkeypatch.setenv("RT_BUILD_THREADS", "1")
+    c = rt.Scene()
+    build(c)
+    flat_c = c.get_flat()
+    ec, rc = c.search_structure()
+    for key in ("nodes", "prim_refs", "tri_pos", "tri_normal", "tri_uv", "tri_mat"):
+        assert np.array_equal(flat[key].view(np.uint32), flat_c[key].view(np.uint32)), key
+    assert np.array_equal(ea, ec) and np.array_equal(ra, rc)
+    compare_scene_arrays(flat, b.dump())
+    check_structure(flat, *b.dump_tree())
+    # an index beyond the vertices refuses the mesh before any of it has been taken in
+    bad = mesh["indices"].copy()
+    bad[-1, 2] = mesh["positions"].shape[0]
+    d = rt.Scene()
+    m = d.add_material(0, (0.5, 0.5, 0.5))
+    with pytest.raises(rt.RtError):
+        d.add_mesh(rt.IDENTITY, mesh["positions"], bad, m)
+    assert d.flatten().n_triangles == 0
