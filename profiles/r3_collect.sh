@@ -15,4 +15,5 @@ RT_TWO_PASS=1 timeout -k 10 100 python profiles/sched_stats.py 16 > gpurun_out/r
 RT_TWO_PASS=0 timeout -k 10 100 python profiles/sched_stats.py 16 > gpurun_out/r3_sched_stats_single_pass.txt 2>&1 || exit 4
 timeout -k 10 100 python profiles/op_ticks.py cover 16 > gpurun_out/r3_op_ticks.txt 2>&1 || exit 5
 timeout -k 10 300 python profiles/op_ticks.py cornell 16 >> gpurun_out/r3_op_ticks.txt 2>&1 || exit 5
+timeout -k 10 600 python profiles/bench_configs.py build:1000000 build:10000000 2> gpurun_out/r3_build_compare.err | grep "^{" > gpurun_out/r3_build_compare.jsonl || exit 6
 echo "all done"
