@@ -24,7 +24,9 @@
 // monotonicity argument).
 #include <algorithm>
 #include <array>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
@@ -333,6 +335,15 @@ void Scene::buildFastStructure() {
     f.tri_ord.assign(triangles.size(), -1);
     const size_t nRefs = f.prim_refs.size();
     const size_t nNodes = f.nodes.size() / 8;
+    // RT_HOST_TIMING=1: the stretches of this function on stderr
+    const bool timing = std::getenv("RT_HOST_TIMING") && std::atoi(std::getenv("RT_HOST_TIMING")) != 0;
+    auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[search structure] %-32s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t0).count());
+        t0 = now;
+    };
 
     // ---- reference visit order of every primitive
     for (size_t i = 0; i < nRefs; i++) {
@@ -343,6 +354,7 @@ void Scene::buildFastStructure() {
         if (r & kRefTriangle) f.tri_ord[id] = (int32_t)i; else f.sphere_ord[id] = (int32_t)i;
     }
 
+    lap("visit order of the primitives");
     // ---- guards: for every leaf run the innermost box-tested entry above it, and for every
     // box-tested entry the nearest enclosing one that does not contain its box
     f.prim_guard.assign(nRefs, -1);
@@ -393,6 +405,7 @@ void Scene::buildFastStructure() {
         }
     }
 
+    lap("guard tables");
     // ---- padded primitive boxes.  The padding is what keeps the fused box test conservative.  That
     // test evaluates plane * inv - origin * inv with the second product rounded first, so in position
     // terms its error is about (3 |origin| + 2 |plane|) * 2^-24.  The |plane| part is covered 800
@@ -471,6 +484,7 @@ void Scene::buildFastStructure() {
         if (f.sphere_ord[i] >= 0) world.push_back({false, i});
     for (size_t i = 0; i < triangles.size(); i++)
         if (f.tri_ord[i] >= 0) world.push_back({true, i});
+    lap("extent, list of primitives");
     std::vector<float> base(world.size());
     parallelPieces(world.size(), [&](size_t first, size_t last) {
         float m = std::numeric_limits<float>::infinity();
@@ -481,6 +495,7 @@ void Scene::buildFastStructure() {
         std::lock_guard<std::mutex> g(fold);
         minPad = std::min(minPad, m);
     });
+    lap("base paddings");
     f.far_spheres = f.far_tris = 0;
     f.far_rmin = 0.0f;
     double farC[3] = {0, 0, 0}, farR = 0.0, rmin = std::numeric_limits<double>::infinity();
@@ -488,31 +503,71 @@ void Scene::buildFastStructure() {
         // the farthest a ray that uses the search structure can start from a primitive: origins are limited
         // to minPad * 2^21 per axis (fastTestUsable), primitives to `extent`
         const double reach = 1.7320508 * ((double)minPad * 2097152.0 + (double)extent) * 1.01;
-        std::vector<std::array<double, 3>> pts;
-        for (size_t w = 0; w < world.size(); w++) {
+        // The points of those primitives (sphere centres, triangle vertices): their number, their mean and the
+        // largest distance from it.  Sums are formed per block of 65,536 primitives and the blocks' sums added in
+        // order, so the mean does not depend on how many threads took part.
+        auto isFar = [&](size_t w) {
             const size_t i = world[w].second;
-            if (!world[w].first) {
-                const double r = std::fabs((double)spheres[i].r);
-                if (phantomSphere(r, reach) <= 0.5 * base[w]) continue;  // covered at any distance
-                f.far_spheres++;
-                rmin = std::min(rmin, r);
-                pts.push_back({spheres[i].c[0], spheres[i].c[1], spheres[i].c[2]});
-            } else {
-                if (kTriErr * reach <= 0.5 * base[w]) continue;
-                f.far_tris++;
-                for (int v = 0; v < 3; v++)
-                    pts.push_back({triangles[i].pos[3 * v], triangles[i].pos[3 * v + 1], triangles[i].pos[3 * v + 2]});
+            if (!world[w].first) return phantomSphere(std::fabs((double)spheres[i].r), reach) > 0.5 * base[w];
+            return kTriErr * reach > 0.5 * base[w];
+        };
+        constexpr size_t kBlock = 65536;
+        const size_t nBlocks = (world.size() + kBlock - 1) / kBlock;
+        struct BlockSum {
+            double c[3] = {0, 0, 0}, rmin = std::numeric_limits<double>::infinity();
+            size_t points = 0;
+            int spheres = 0, tris = 0;
+        };
+        std::vector<BlockSum> sums(nBlocks);
+        parallelPieces(nBlocks, [&](size_t firstBlock, size_t lastBlock) {
+            for (size_t blk = firstBlock; blk < lastBlock; blk++) {
+                BlockSum& bs = sums[blk];
+                for (size_t w = blk * kBlock; w < std::min(world.size(), (blk + 1) * kBlock); w++) {
+                    if (!isFar(w)) continue;  // covered at any distance
+                    const size_t i = world[w].second;
+                    if (!world[w].first) {
+                        bs.spheres++;
+                        bs.rmin = std::min(bs.rmin, std::fabs((double)spheres[i].r));
+                        for (int k = 0; k < 3; k++) bs.c[k] += spheres[i].c[k];
+                        bs.points++;
+                    } else {
+                        bs.tris++;
+                        for (int v = 0; v < 3; v++)
+                            for (int k = 0; k < 3; k++) bs.c[k] += triangles[i].pos[3 * v + k];
+                        bs.points += 3;
+                    }
+                }
             }
+        });
+        size_t nPoints = 0;
+        for (const BlockSum& bs : sums) {
+            f.far_spheres += bs.spheres;
+            f.far_tris += bs.tris;
+            rmin = std::min(rmin, bs.rmin);
+            nPoints += bs.points;
+            for (int k = 0; k < 3; k++) farC[k] += bs.c[k];
         }
-        for (const auto& q : pts)
-            for (int k = 0; k < 3; k++) farC[k] += q[k];
-        if (!pts.empty()) {
-            for (int k = 0; k < 3; k++) farC[k] /= (double)pts.size();
-            for (const auto& q : pts) {
-                double d2 = 0;
-                for (int k = 0; k < 3; k++) d2 += (q[k] - farC[k]) * (q[k] - farC[k]);
-                farR = std::max(farR, std::sqrt(d2));
-            }
+        if (nPoints) {
+            for (int k = 0; k < 3; k++) farC[k] /= (double)nPoints;
+            std::mutex foldFar;
+            parallelPieces(world.size(), [&](size_t first, size_t last) {
+                double far2 = 0.0;
+                auto reachOf = [&](const float* q) {
+                    double d2 = 0;
+                    for (int k = 0; k < 3; k++) d2 += ((double)q[k] - farC[k]) * ((double)q[k] - farC[k]);
+                    far2 = std::max(far2, d2);
+                };
+                for (size_t w = first; w < last; w++) {
+                    if (!isFar(w)) continue;
+                    const size_t i = world[w].second;
+                    if (!world[w].first)
+                        reachOf(spheres[i].c);
+                    else
+                        for (int v = 0; v < 3; v++) reachOf(&triangles[i].pos[3 * v]);
+                }
+                std::lock_guard<std::mutex> g(foldFar);
+                farR = std::max(farR, std::sqrt(far2));
+            });
         }
     }
     // the distance budgeted for: from the eye to the far side of those primitives, or across them
@@ -524,6 +579,7 @@ void Scene::buildFastStructure() {
     f.far_radius = (float)(farR * 1.001 + 1e-6);
     f.far_rmin = f.far_spheres ? (float)rmin : 0.0f;
     f.far_typical = (float)dTyp;
+    lap("primitives far rays must widen for");
     // pass 2: the padded boxes
     f.world_refs.resize(world.size());
     if (!deferred) prims.resize(world.size());
@@ -557,6 +613,7 @@ void Scene::buildFastStructure() {
     });
     f.fast_min_pad = minPad;
     f.pad_floor = originFloor;
+    lap("padded boxes");
     if (deferred && !f.world_refs.empty()) return;
     if (prims.empty()) {
         // nothing to search: one entry with an inverted box and no leaf run (whatever its test
