@@ -18,7 +18,8 @@
 // out (clustering build only: a Morton-split tree has long chains of nearly equal boxes, and judged against
 // their parents that rule flattened them into scans of hundreds of siblings, 462 box tests per ray).
 // Measured on the vase scenes, host surface-area build = 1: Morton-split 1.55 (1 M triangles) / 1.57 (10 M) of its
-// frame time, clustering 1.27 / 1.23, + left-out entries 1.19 / 1.23, + eye order 1.19 / 1.12; build 9 / 15 ms.
+// frame time, clustering 1.27 / 1.23, + left-out entries 1.19 / 1.23, + eye order 1.19 / 1.12, + the top of the
+// tree (the last 8,192 clusters) built top-down on the host and a search radius of 64: 1.06 / 1.06; build 14 / 23 ms.
 //
 // Hand-offs between threads of one launch are avoided on purpose: the bottom-up pass runs as one
 // launch per tree level (a node is computed in the launch after both its children were), so every
@@ -31,6 +32,7 @@
 #include <cstdlib>
 #include <algorithm>
 #include <functional>
+#include <limits>
 #include <string>
 #include <vector>
 
@@ -230,7 +232,7 @@ __global__ void __launch_bounds__(256) fitLevel(Tree t, const float4* pbox, int 
 // ---------------------------------------------------------------------------------------
 // Agglomerative build by parallel locally-ordered clustering (Meister and Bittner, "Parallel locally-ordered
 // clustering for bounding volume hierarchy construction", 2018), the default: the Morton-sorted primitives
-// are the first clusters; in every round each cluster looks at its `radius` neighbours to either side in the
+// are the first clusters; in every round each cluster looks at its `radius` (64) neighbours to either side in the
 // array for the one whose union with it has the smallest surface area, pairs that chose each other are
 // merged into a new node that takes the place of the first of the two, and the array is compacted.  The
 // comparison key is (area, lower position, higher position), which no two pairs share, so the pair with the
@@ -262,6 +264,50 @@ __device__ __forceinline__ float unionArea(const float4& amn, const float4& amx,
     const float dx = fmaxf(amx.x, bmx.x) - fminf(amn.x, bmn.x), dy = fmaxf(amx.y, bmx.y) - fminf(amn.y, bmn.y),
                 dz = fmaxf(amx.z, bmx.z) - fminf(amn.z, bmn.z);
     return dx * dy + dy * dz + dz * dx;
+}
+
+// A new inner node over the children lc and rc (codes as in Tree::left) with boxes a and b: links both ways, box,
+// area, the order its children are visited in for every direction octant and from the eye, and the entry and
+// primitive counts below it.  Both children were finished by earlier launches.
+__device__ __forceinline__ void makeNode(const Tree& t, int node, int lc, int rc, const float4& amn, const float4& amx, const float4& bmn,
+                                         const float4& bmx, const float* eye, float4& mn, float4& mx) {
+    mn = make_float4(fminf(amn.x, bmn.x), fminf(amn.y, bmn.y), fminf(amn.z, bmn.z), 0.f);
+    mx = make_float4(fmaxf(amx.x, bmx.x), fmaxf(amx.y, bmx.y), fmaxf(amx.z, bmx.z), 0.f);
+    t.left[node] = lc;
+    t.right[node] = rc;
+    t.parent[lc < 0 ? (t.n - 1) + ~lc : lc] = node;
+    t.parent[rc < 0 ? (t.n - 1) + ~rc : rc] = node;
+    t.parent[node] = -1;  // until a later round gives it one
+    t.nbox[2 * (size_t)node] = mn;
+    t.nbox[2 * (size_t)node + 1] = mx;
+    unsigned mask = 0;  // for every sign pattern of the ray direction: is the right child's box entered first?
+    for (int k = 0; k < 8; k++) {
+        const float al = ((k & 1) ? -amx.x : amn.x) + ((k & 2) ? -amx.y : amn.y) + ((k & 4) ? -amx.z : amn.z);
+        const float ar = ((k & 1) ? -bmx.x : bmn.x) + ((k & 2) ? -bmx.y : bmn.y) + ((k & 4) ? -bmx.z : bmn.z);
+        if (ar < al) mask |= 1u << k;
+    }
+    {
+        // the single copy: the child whose box is nearer to the eye first, the larger one on a tie (host builder's rule)
+        auto eyeDist2 = [&](const float4& bn, const float4& bx) {
+            const float dx = fmaxf(0.0f, fmaxf(bn.x - eye[0], eye[0] - bx.x)), dy = fmaxf(0.0f, fmaxf(bn.y - eye[1], eye[1] - bx.y)),
+                        dz = fmaxf(0.0f, fmaxf(bn.z - eye[2], eye[2] - bx.z));
+            return dx * dx + dy * dy + dz * dz;
+        };
+        auto halfArea = [](const float4& bn, const float4& bx) {
+            const float dx = bx.x - bn.x, dy = bx.y - bn.y, dz = bx.z - bn.z;
+            return dx * dy + dy * dz + dz * dx;
+        };
+        const float dl = eyeDist2(amn, amx), dr = eyeDist2(bmn, bmx);
+        if (dl == dr ? halfArea(amn, amx) < halfArea(bmn, bmx) : dl > dr) mask |= 1u << 8;
+    }
+    t.rfirst[node] = (uint16_t)mask;
+    const int cl = lc < 0 ? 1 : t.count[lc], cr = rc < 0 ? 1 : t.count[rc];
+    t.count[node] = (lc < 0 && rc < 0) ? 1 : 1 + cl + cr;
+    t.lcount[node] = (lc < 0 ? 1 : t.lcount[lc]) + (rc < 0 ? 1 : t.lcount[rc]);
+    {
+        const float dx = mx.x - mn.x, dy = mx.y - mn.y, dz = mx.z - mn.z;
+        t.area[node] = dx * dy + dy * dz + dz * dx;
+    }
 }
 
 __global__ void __launch_bounds__(256) plocInit(Tree t, const float4* pbox, int* cid, float4* cbox, int* state) {
@@ -331,50 +377,133 @@ __global__ void __launch_bounds__(256) plocMerge(Ploc a) {
     }
     const int j = a.nn[i];
     const int node = a.stateIn[1] + (int)(unsigned)(sc >> 32);
-    const int lc = a.cidIn[i], rc = a.cidIn[j];
-    const float4 amn = a.cboxIn[2 * (size_t)i], amx = a.cboxIn[2 * (size_t)i + 1];
-    const float4 bmn = a.cboxIn[2 * (size_t)j], bmx = a.cboxIn[2 * (size_t)j + 1];
-    const float4 mn = make_float4(fminf(amn.x, bmn.x), fminf(amn.y, bmn.y), fminf(amn.z, bmn.z), 0.f);
-    const float4 mx = make_float4(fmaxf(amx.x, bmx.x), fmaxf(amx.y, bmx.y), fmaxf(amx.z, bmx.z), 0.f);
-    t.left[node] = lc;
-    t.right[node] = rc;
-    t.parent[lc < 0 ? (t.n - 1) + ~lc : lc] = node;
-    t.parent[rc < 0 ? (t.n - 1) + ~rc : rc] = node;
-    t.parent[node] = -1;  // until a later round gives it one
-    t.nbox[2 * (size_t)node] = mn;
-    t.nbox[2 * (size_t)node + 1] = mx;
-    unsigned mask = 0;  // for every sign pattern of the ray direction: is the right child's box entered first?
-    for (int k = 0; k < 8; k++) {
-        const float al = ((k & 1) ? -amx.x : amn.x) + ((k & 2) ? -amx.y : amn.y) + ((k & 4) ? -amx.z : amn.z);
-        const float ar = ((k & 1) ? -bmx.x : bmn.x) + ((k & 2) ? -bmx.y : bmn.y) + ((k & 4) ? -bmx.z : bmn.z);
-        if (ar < al) mask |= 1u << k;
-    }
-    {
-        // the single copy: the child whose box is nearer to the eye first, the larger one on a tie (host builder's rule)
-        auto eyeDist2 = [&](const float4& bn, const float4& bx) {
-            const float dx = fmaxf(0.0f, fmaxf(bn.x - a.eye[0], a.eye[0] - bx.x)), dy = fmaxf(0.0f, fmaxf(bn.y - a.eye[1], a.eye[1] - bx.y)),
-                        dz = fmaxf(0.0f, fmaxf(bn.z - a.eye[2], a.eye[2] - bx.z));
-            return dx * dx + dy * dy + dz * dz;
-        };
-        auto halfArea = [](const float4& bn, const float4& bx) {
-            const float dx = bx.x - bn.x, dy = bx.y - bn.y, dz = bx.z - bn.z;
-            return dx * dy + dy * dz + dz * dx;
-        };
-        const float dl = eyeDist2(amn, amx), dr = eyeDist2(bmn, bmx);
-        if (dl == dr ? halfArea(amn, amx) < halfArea(bmn, bmx) : dl > dr) mask |= 1u << 8;
-    }
-    t.rfirst[node] = (uint16_t)mask;
-    const int cl = lc < 0 ? 1 : t.count[lc], cr = rc < 0 ? 1 : t.count[rc];
-    t.count[node] = (lc < 0 && rc < 0) ? 1 : 1 + cl + cr;
-    t.lcount[node] = (lc < 0 ? 1 : t.lcount[lc]) + (rc < 0 ? 1 : t.lcount[rc]);
-    {
-        const float dx = mx.x - mn.x, dy = mx.y - mn.y, dz = mx.z - mn.z;
-        t.area[node] = dx * dy + dy * dz + dz * dx;
-    }
+    float4 mn, mx;
+    makeNode(t, node, a.cidIn[i], a.cidIn[j], a.cboxIn[2 * (size_t)i], a.cboxIn[2 * (size_t)i + 1], a.cboxIn[2 * (size_t)j],
+             a.cboxIn[2 * (size_t)j + 1], a.eye, mn, mx);
     a.cidOut[pos] = node;
     a.cboxOut[2 * pos] = mn;
     a.cboxOut[2 * pos + 1] = mx;
 }
+
+// ---- the top of the tree.  Bottom-up clustering is at its weakest where few, large clusters are left: a pair
+// is merged because it is the best one in sight, not because the split it makes of everything above is a good
+// one, and every ray pays for those entries.  So the rounds stop when a few thousand clusters are left; those
+// go to the host, which builds the tree over them top-down by the surface-area heuristic (every split position
+// along every axis tried: the clusters are few), and the nodes come back as child pairs, numbered by height, to
+// be finished one height per launch like a round's nodes.
+__global__ void __launch_bounds__(256) clusterWeights(Tree t, const int* cid, int m, int* weight) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const int c = cid[i];
+    weight[i] = c < 0 ? 1 : t.lcount[c];
+}
+
+__global__ void __launch_bounds__(256) topNodes(Tree t, const float4* pbox, int lo, int hi, const int2* children, float ex, float ey, float ez) {
+    const int node = lo + blockIdx.x * blockDim.x + threadIdx.x;
+    if (node >= hi) return;
+    const int2 c = children[node - lo];
+    auto boxOf = [&](int code, float4& bn, float4& bx) {
+        if (code < 0) {
+            const size_t p = t.order[~code];
+            bn = pbox[2 * p];
+            bx = pbox[2 * p + 1];
+        } else {
+            bn = t.nbox[2 * (size_t)code];
+            bx = t.nbox[2 * (size_t)code + 1];
+        }
+    };
+    float4 amn, amx, bmn, bmx, mn, mx;
+    boxOf(c.x, amn, amx);
+    boxOf(c.y, bmn, bmx);
+    const float eye[3] = {ex, ey, ez};
+    makeNode(t, node, c.x, c.y, amn, amx, bmn, bmx, eye, mn, mx);
+}
+
+struct TopCluster {
+    float mn[3], mx[3];
+    int code;    // child code of the cluster (Tree::left)
+    int weight;  // primitives below it
+};
+struct TopNode {
+    int left, right;  // >= 0: cluster number, < 0: ~(top node number)
+    int height;       // 1 + the larger of the children's (clusters: 0)
+};
+
+// Top-down surface-area build over clusters[lo, hi) (reordered in place); returns the child reference of the subtree.
+// Cost of a split = area(left) * primitives(left) + area(right) * primitives(right), every position of the
+// clusters sorted by centre along every axis; ties go to the earlier axis and position.
+struct TopBuilder {
+    std::vector<TopCluster>& clusters;
+    std::vector<TopNode>& nodes;
+    std::vector<float> suffix;
+    std::vector<TopCluster> sorted;
+
+    static float halfArea(const float* mn, const float* mx) {
+        const float dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
+        return dx * dy + dy * dz + dz * dx;
+    }
+    static void grow(float* mn, float* mx, const TopCluster& c) {
+        for (int k = 0; k < 3; k++) {
+            mn[k] = std::min(mn[k], c.mn[k]);
+            mx[k] = std::max(mx[k], c.mx[k]);
+        }
+    }
+    static void sortAlong(std::vector<TopCluster>::iterator first, std::vector<TopCluster>::iterator last, int axis) {
+        std::stable_sort(first, last, [axis](const TopCluster& a, const TopCluster& b) { return a.mn[axis] + a.mx[axis] < b.mn[axis] + b.mx[axis]; });
+    }
+    // sorts clusters[lo, hi) along the best axis and returns the number that go left; equal costs go to the
+    // earlier axis and the more even split
+    size_t split(size_t lo, size_t hi) {
+        const size_t cnt = hi - lo;
+        const float inf = std::numeric_limits<float>::infinity();
+        double bestCost = std::numeric_limits<double>::infinity();
+        size_t bestAt = cnt / 2;
+        int bestAxis = -1;
+        auto uneven = [cnt](size_t k) { return k > cnt - k ? 2 * k - cnt : cnt - 2 * k; };
+        suffix.resize(cnt + 1);
+        for (int axis = 0; axis < 3; axis++) {
+            sorted.assign(clusters.begin() + (long)lo, clusters.begin() + (long)hi);
+            sortAlong(sorted.begin(), sorted.end(), axis);
+            float mn[3] = {inf, inf, inf}, mx[3] = {-inf, -inf, -inf};
+            for (size_t k = cnt; k-- > 0;) {
+                grow(mn, mx, sorted[k]);
+                suffix[k] = halfArea(mn, mx);
+            }
+            for (int k = 0; k < 3; k++) {
+                mn[k] = inf;
+                mx[k] = -inf;
+            }
+            long long wl = 0, wt = 0;
+            for (size_t k = 0; k < cnt; k++) wt += sorted[k].weight;
+            for (size_t k = 1; k < cnt; k++) {
+                grow(mn, mx, sorted[k - 1]);
+                wl += sorted[k - 1].weight;
+                const double cost = (double)halfArea(mn, mx) * (double)wl + (double)suffix[k] * (double)(wt - wl);
+                if (cost < bestCost || (cost == bestCost && axis == bestAxis && uneven(k) < uneven(bestAt))) {
+                    bestCost = cost;
+                    bestAt = k;
+                    bestAxis = axis;
+                }
+            }
+        }
+        if (bestAxis >= 0) sortAlong(clusters.begin() + (long)lo, clusters.begin() + (long)hi, bestAxis);
+        return bestAt;
+    }
+    // (below 64 levels of one-sided splits the halves are taken as they lie: bounds the work on degenerate input)
+    int build(size_t lo, size_t hi, int depth, int* height) {
+        if (hi - lo == 1) {
+            *height = 0;
+            return (int)lo;
+        }
+        const size_t k = depth < 64 ? split(lo, hi) : (hi - lo) / 2;
+        int hl = 0, hr = 0;
+        const int l = build(lo, lo + k, depth + 1, &hl);
+        const int r = build(lo + k, hi, depth + 1, &hr);
+        *height = 1 + std::max(hl, hr);
+        nodes.push_back({l, r, *height});
+        return ~(int)(nodes.size() - 1);
+    }
+};
 
 // Which nodes get an entry (the host builder's rule, fast_bvh.cpp: Emission::gather): a node over two subtrees whose
 // box has more than half the area of the entry above it would pass nearly every ray that entry passes, so it is
@@ -549,7 +678,7 @@ hipError_t buildSearchStructureOnDevice(int n, const uint32_t* d_refs, const flo
     const char* treeEnv = std::getenv("RT_DEVICE_TREE");
     const bool ploc = !(treeEnv && std::string(treeEnv) == "lbvh");
     const char* radiusEnv = std::getenv("RT_PLOC_RADIUS");
-    const int radius = std::max(1, std::min(64, radiusEnv ? std::atoi(radiusEnv) : 10));
+    const int radius = std::max(1, std::min(512, radiusEnv ? std::atoi(radiusEnv) : 64));
     uint16_t* rfirst = nullptr;
     void* sortTemp = nullptr;
     size_t sortBytes = 0;
@@ -626,7 +755,11 @@ hipError_t buildSearchStructureOnDevice(int n, const uint32_t* d_refs, const flo
         int* stateIn = state;
         int* stateOut = state + 8;
         int rounds = 0;
-        for (int round = 0; e == hipSuccess && m > 1; round++, rounds++) {
+        // RT_DEVICE_TOP: the clustering stops at this many clusters (and a sixteenth of the primitives at most) and
+        // the host builds the tree above them; 0 or 1 = clustering all the way up
+        const int topWanted = std::getenv("RT_DEVICE_TOP") ? std::atoi(std::getenv("RT_DEVICE_TOP")) : 8192;
+        const int topStop = std::max(1, std::min(topWanted, n / 16));
+        for (int round = 0; e == hipSuccess && m > topStop; round++, rounds++) {
             if (round >= kMaxRounds) {
                 e = hipErrorUnknown;  // every round merges at least one pair
                 break;
@@ -644,7 +777,7 @@ hipError_t buildSearchStructureOnDevice(int n, const uint32_t* d_refs, const flo
             std::swap(cidA, cidB);
             std::swap(cboxA, cboxB);
             std::swap(stateIn, stateOut);
-            if ((round & 3) == 3 || m <= 4096) {  // how many are left, every fourth round (every round near the end)
+            if ((round & 3) == 3 || m <= std::max(4096, 4 * topStop)) {  // how many are left, every fourth round (every round near the end)
                 int st[2] = {0, 0};
                 if (e == hipSuccess) e = hipMemcpyAsync(st, stateIn, sizeof st, hipMemcpyDeviceToHost, stream);
                 if (e == hipSuccess) e = hipStreamSynchronize(stream);
@@ -655,6 +788,58 @@ hipError_t buildSearchStructureOnDevice(int n, const uint32_t* d_refs, const flo
         std::vector<int> base((size_t)rounds + 1, 0);
         if (e == hipSuccess && rounds > 0) e = hipMemcpyAsync(base.data(), roundBase, base.size() * sizeof(int), hipMemcpyDeviceToHost, stream);
         if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        std::vector<int2> topChildren;
+        if (e == hipSuccess && m > 1) {
+            // the top of the tree: the m clusters that are left go to the host (TopBuilder) and come back as nodes
+            const int made = n - m;  // every merge took one cluster away
+            if (base.back() != made) e = hipErrorUnknown;
+            std::vector<int> code((size_t)m), weight((size_t)m);
+            std::vector<float4> cbox(2 * (size_t)m);
+            if (e == hipSuccess) {
+                clusterWeights<<<(m + 255) / 256, 256, 0, stream>>>(t, cidA, m, nn);
+                e = hipGetLastError();
+            }
+            if (e == hipSuccess) e = hipMemcpyAsync(code.data(), cidA, (size_t)m * sizeof(int), hipMemcpyDeviceToHost, stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(weight.data(), nn, (size_t)m * sizeof(int), hipMemcpyDeviceToHost, stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(cbox.data(), cboxA, 2 * (size_t)m * sizeof(float4), hipMemcpyDeviceToHost, stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(stream);
+            if (e == hipSuccess) {
+                std::vector<TopCluster> clusters((size_t)m);
+                for (size_t i = 0; i < (size_t)m; i++) {
+                    const float4 bn = cbox[2 * i], bx = cbox[2 * i + 1];
+                    clusters[i] = {{bn.x, bn.y, bn.z}, {bx.x, bx.y, bx.z}, code[i], weight[i]};
+                }
+                std::vector<TopNode> top;
+                top.reserve((size_t)m);
+                int height = 0;
+                TopBuilder{clusters, top, {}, {}}.build(0, (size_t)m, 0, &height);
+                // numbered by height, so that a node's children have smaller numbers and the root the last one
+                std::vector<int> byHeight(top.size()), number(top.size());
+                for (size_t j = 0; j < top.size(); j++) byHeight[j] = (int)j;
+                std::stable_sort(byHeight.begin(), byHeight.end(), [&](int x, int y) { return top[(size_t)x].height < top[(size_t)y].height; });
+                for (size_t r = 0; r < byHeight.size(); r++) number[(size_t)byHeight[r]] = made + (int)r;
+                topChildren.resize(top.size());
+                auto codeOf = [&](int child) { return child >= 0 ? clusters[(size_t)child].code : number[(size_t)~child]; };
+                for (size_t r = 0; r < byHeight.size(); r++) {
+                    const TopNode& tn = top[(size_t)byHeight[r]];
+                    topChildren[r] = make_int2(codeOf(tn.left), codeOf(tn.right));
+                }
+                int2* dChildren = reinterpret_cast<int2*>(flags);  // free again: at least as large as the node count
+                e = hipMemcpyAsync(dChildren, topChildren.data(), topChildren.size() * sizeof(int2), hipMemcpyHostToDevice, stream);
+                for (size_t r = 0; r < byHeight.size() && e == hipSuccess;) {
+                    size_t q = r;
+                    while (q < byHeight.size() && top[(size_t)byHeight[q]].height == top[(size_t)byHeight[r]].height) q++;
+                    const int lo = made + (int)r, hi = made + (int)q;
+                    topNodes<<<(hi - lo + 255) / 256, 256, 0, stream>>>(t, pbox, lo, hi, dChildren + r, eye[0], eye[1], eye[2]);
+                    e = hipGetLastError();
+                    base.push_back(hi);  // one more "round" for the two passes below
+                    r = q;
+                }
+                if (e == hipSuccess) e = hipStreamSynchronize(stream);
+                if (e == hipSuccess && base.back() != n - 1) e = hipErrorUnknown;
+            }
+        }
+        rounds = (int)base.size() - 1;
         // RT_DEVICE_COLLAPSE: the area ratio above which an inner node is left out (0 = keep every node)
         const float collapse = std::getenv("RT_DEVICE_COLLAPSE") ? (float)std::atof(std::getenv("RT_DEVICE_COLLAPSE")) : 0.5f;
         if (collapse > 0.0f) {
