@@ -367,14 +367,27 @@ void Scene::buildFastStructure() {
         f.world_refs.clear();
         return;
     }
-    std::vector<int> open;  // stack of box-tested entries whose subtree contains the current entry
     auto box = [&](int e, float* mn, float* mx) {
         for (int k = 0; k < 3; k++) {
             mn[k] = f32(f.nodes[(size_t)e * 8 + k]);
             mx[k] = f32(f.nodes[(size_t)e * 8 + 4 + k]);
         }
     };
-    for (size_t e = 0; e < nNodes; e++) {
+    // (in pieces on the builders' threads: every entry and every leaf run is written by the piece its entry lies in)
+    parallelPieces(nNodes, [&](size_t firstEntry, size_t lastEntry) {
+    std::vector<int> open;  // stack of box-tested entries whose subtree contains the current entry
+    // the stack as the entries before this piece left it: down from the first entry along the skip links
+    for (size_t x = 0; x < firstEntry;) {
+        const uint32_t w3 = f.nodes[x * 8 + 3];
+        const size_t skip = w3 & kNodeSkipMask;
+        if (skip > firstEntry) {
+            if (!(w3 & kNodeNoBox)) open.push_back((int)x);
+            x++;
+        } else {
+            x = skip;
+        }
+    }
+    for (size_t e = firstEntry; e < lastEntry; e++) {
         while (!open.empty() && (f.nodes[(size_t)open.back() * 8 + 3] & kNodeSkipMask) <= e) open.pop_back();
         const uint32_t w3 = f.nodes[e * 8 + 3];
         const bool hasBox = !(w3 & kNodeNoBox);
@@ -404,6 +417,7 @@ void Scene::buildFastStructure() {
             }
         }
     }
+    });
 
     lap("guard tables");
     // ---- padded primitive boxes.  The padding is what keeps the fused box test conservative.  That
@@ -479,17 +493,20 @@ void Scene::buildFastStructure() {
     };
     // pass 1: base paddings, the smallest of them, and the primitives whose base padding does not also cover
     // their own test's inaccuracy at every distance a ray of this scene can start from
-    std::vector<std::pair<bool, size_t>> world;  // (triangle?, id) in the order of world_refs
+    std::vector<uint32_t>& world = f.world_refs;  // the primitives that are in the world: spheres, then triangles
+    world.reserve(spheres.size() + triangles.size());
     for (size_t i = 0; i < spheres.size(); i++)
-        if (f.sphere_ord[i] >= 0) world.push_back({false, i});
+        if (f.sphere_ord[i] >= 0) world.push_back((uint32_t)i);
     for (size_t i = 0; i < triangles.size(); i++)
-        if (f.tri_ord[i] >= 0) world.push_back({true, i});
+        if (f.tri_ord[i] >= 0) world.push_back((uint32_t)i | kRefTriangle);
+    auto isTri = [&](size_t w) { return (world[w] & kRefTriangle) != 0; };
+    auto idOf = [&](size_t w) { return (size_t)(world[w] & kRefIdMask); };
     lap("extent, list of primitives");
     std::vector<float> base(world.size());
     parallelPieces(world.size(), [&](size_t first, size_t last) {
         float m = std::numeric_limits<float>::infinity();
         for (size_t w = first; w < last; w++) {
-            base[w] = basePad(primBox(world[w].first, world[w].second));
+            base[w] = basePad(primBox(isTri(w), idOf(w)));
             m = std::min(m, base[w]);
         }
         std::lock_guard<std::mutex> g(fold);
@@ -507,8 +524,8 @@ void Scene::buildFastStructure() {
         // largest distance from it.  Sums are formed per block of 65,536 primitives and the blocks' sums added in
         // order, so the mean does not depend on how many threads took part.
         auto isFar = [&](size_t w) {
-            const size_t i = world[w].second;
-            if (!world[w].first) return phantomSphere(std::fabs((double)spheres[i].r), reach) > 0.5 * base[w];
+            const size_t i = idOf(w);
+            if (!isTri(w)) return phantomSphere(std::fabs((double)spheres[i].r), reach) > 0.5 * base[w];
             return kTriErr * reach > 0.5 * base[w];
         };
         constexpr size_t kBlock = 65536;
@@ -524,8 +541,8 @@ void Scene::buildFastStructure() {
                 BlockSum& bs = sums[blk];
                 for (size_t w = blk * kBlock; w < std::min(world.size(), (blk + 1) * kBlock); w++) {
                     if (!isFar(w)) continue;  // covered at any distance
-                    const size_t i = world[w].second;
-                    if (!world[w].first) {
+                    const size_t i = idOf(w);
+                    if (!isTri(w)) {
                         bs.spheres++;
                         bs.rmin = std::min(bs.rmin, std::fabs((double)spheres[i].r));
                         for (int k = 0; k < 3; k++) bs.c[k] += spheres[i].c[k];
@@ -559,8 +576,8 @@ void Scene::buildFastStructure() {
                 };
                 for (size_t w = first; w < last; w++) {
                     if (!isFar(w)) continue;
-                    const size_t i = world[w].second;
-                    if (!world[w].first)
+                    const size_t i = idOf(w);
+                    if (!isTri(w))
                         reachOf(spheres[i].c);
                     else
                         for (int v = 0; v < 3; v++) reachOf(&triangles[i].pos[3 * v]);
@@ -581,7 +598,6 @@ void Scene::buildFastStructure() {
     f.far_typical = (float)dTyp;
     lap("primitives far rays must widen for");
     // pass 2: the padded boxes
-    f.world_refs.resize(world.size());
     if (!deferred) prims.resize(world.size());
     parallelPieces(world.size(), [&](size_t first, size_t last) {
         float cmn[3], cmx[3];
@@ -590,14 +606,13 @@ void Scene::buildFastStructure() {
             cmx[k] = -std::numeric_limits<float>::infinity();
         }
         for (size_t w = first; w < last; w++) {
-            PrimBox b = primBox(world[w].first, world[w].second);
-            f.world_refs[w] = b.ref;
+            PrimBox b = primBox(isTri(w), idOf(w));
             for (int k = 0; k < 3; k++) {
                 const float c = 0.5f * (b.mn[k] + b.mx[k]);
                 cmn[k] = std::min(cmn[k], c);
                 cmx[k] = std::max(cmx[k], c);
             }
-            const double far = world[w].first ? kTriErr * dTyp : phantomSphere(std::fabs((double)spheres[world[w].second].r), dTyp);
+            const double far = isTri(w) ? kTriErr * dTyp : phantomSphere(std::fabs((double)spheres[idOf(w)].r), dTyp);
             const float d = (float)((double)base[w] + far * 1.01);
             for (int k = 0; k < 3; k++) {
                 b.mn[k] -= d;

@@ -542,6 +542,8 @@ int Scene::buildBvh(Composite& c, std::vector<BoxedObj>& objs, size_t start, siz
     c.nodes.resize(base + total);
     std::atomic<int> spare((int)buildThreads() - 1);
     buildBvhAt(c, objs, start, end, max_depth, base, axes, spare);
+    c.built_first = base;
+    c.built_count = total;
     return (int)base;
 }
 
@@ -1318,9 +1320,78 @@ void Scene::emitBvhNode(const Composite& c, int node) {
     flat.nodes[(size_t)e * 8 + 3] = end;  // a miss jumps past the whole subtree
 }
 
+// emitBvhNode for a large tree that buildBvh made and whose leaves hold primitives only: its nodes lie in pre-order,
+// so node k of the tree is entry k of its block, a subtree's end follows from the parents before it, and a leaf
+// run starts where the leaves before it end.  One sequential pass over the node headers for those two numbers, then
+// the entries and runs are written in pieces on the builders' threads.  False (and nothing emitted) when a leaf
+// holds anything but primitives or the numbering is not the expected one.
+bool Scene::emitBvhFlat(const Composite& c) {
+    const size_t N = c.built_count, root = (size_t)c.root;
+    std::vector<uint32_t> endOf(N), runAt(N);
+    endOf[0] = (uint32_t)N;
+    size_t refs = 0;
+    for (size_t i = 0; i < N; i++) {
+        const BvhNode& n = c.nodes[root + i];
+        runAt[i] = (uint32_t)refs;
+        if (n.left >= 0) {
+            const size_t l = (size_t)n.left - root, r = (size_t)n.right - root;
+            if (l != i + 1 || r <= l || r >= endOf[i]) return false;
+            endOf[l] = (uint32_t)r;
+            endOf[r] = endOf[i];
+        } else {
+            if (n.leaf.empty() || endOf[i] != i + 1) return false;
+            refs += n.leaf.size();
+        }
+    }
+    const size_t entryBase = flat.nodes.size() / 8, refBase = flat.prim_refs.size();
+    if (entryBase + N >= kNodeSkipMask || refBase + refs >= kRefIdMask) return false;
+    flat.nodes.resize((entryBase + N) * 8);
+    flat.prim_refs.resize(refBase + refs);
+    std::atomic<bool> plain(true);
+    std::atomic<int> longest(0);
+    parallelPieces(N, [&](size_t first, size_t last) {
+        int mine = 0;
+        for (size_t i = first; i < last; i++) {
+            const BvhNode& n = c.nodes[root + i];
+            uint32_t* w = &flat.nodes[(entryBase + i) * 8];
+            for (int k = 0; k < 3; k++) {
+                w[k] = bitsOf(n.box.mn[k]);
+                w[4 + k] = bitsOf(n.box.mx[k]);
+            }
+            w[3] = (uint32_t)(entryBase + endOf[i]);  // a miss jumps past the whole subtree
+            w[7] = 0xFFFFFFFFu;
+            if (n.left >= 0) continue;
+            uint32_t* run = &flat.prim_refs[refBase + runAt[i]];
+            for (size_t j = 0; j < n.leaf.size(); j++) {
+                const Obj& o = n.leaf[j];
+                if (o.kind != Obj::SPHERE && o.kind != Obj::TRIANGLE) {
+                    plain.store(false);
+                    return;
+                }
+                run[j] = (uint32_t)o.id | (o.kind == Obj::TRIANGLE ? kRefTriangle : 0u);
+            }
+            run[n.leaf.size() - 1] |= kRefLast;
+            w[7] = (uint32_t)(refBase + runAt[i]);
+            mine = std::max(mine, (int)n.leaf.size());
+        }
+        int seen = longest.load();
+        while (mine > seen && !longest.compare_exchange_weak(seen, mine)) {}
+    });
+    if (!plain.load()) {
+        flat.nodes.resize(entryBase * 8);
+        flat.prim_refs.resize(refBase);
+        return false;
+    }
+    flat.max_leaf = std::max(flat.max_leaf, longest.load());
+    if (std::getenv("RT_HOST_TIMING") && std::atoi(std::getenv("RT_HOST_TIMING")) != 0)
+        std::fprintf(stderr, "[flatten] a built tree of %zu nodes emitted in pieces\n", N);
+    return true;
+}
+
 void Scene::emitComposite(const Composite& c) {
     if (c.kind == Composite::BVH) {
-        emitBvhNode(c, c.root);
+        const bool large = c.built_count >= 65536 && (size_t)c.root == c.built_first;
+        if (!(large && emitBvhFlat(c))) emitBvhNode(c, c.root);
     } else if (c.kind == Composite::MESH) {
         int e = newEntry(&c.box);
         emitObjects(c.objs, e);

@@ -35,6 +35,9 @@ struct Composite {
     std::vector<Obj> objs;   // MESH / LIST children in order
     std::vector<BvhNode> nodes;  // BVH only
     int root = -1;
+    // nodes[built_first, built_first + built_count) were made by one call of Scene::buildBvh: numbered in pre-order,
+    // every leaf non-empty.  0 for trees that arrive node by node through the API.
+    size_t built_first = 0, built_count = 0;
 };
 
 // Instancing (opt-in; the reference has none: it bakes every placement into world-space triangles,
@@ -240,6 +243,7 @@ private:
     void emitObjects(const std::vector<Obj>& objs, int parent_entry);
     void emitComposite(const Composite& c);
     void emitBvhNode(const Composite& c, int node);
+    bool emitBvhFlat(const Composite& c);
     int newEntry(const Box3* box);
     std::mt19937 gen_;
 };
