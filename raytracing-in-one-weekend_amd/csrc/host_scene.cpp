@@ -500,7 +500,10 @@ void Scene::buildBvhAt(Composite& c, std::vector<BoxedObj>& objs, size_t start, 
         bl = a.box;
         br = b.box;
     } else {
-        std::sort(objs.begin() + start, objs.begin() + end, less);
+        if (span >= 32768)
+            sortLikeStdSort(objs.data() + start, objs.data() + end, less, spare_threads);
+        else
+            std::sort(objs.begin() + start, objs.begin() + end, less);
         size_t mid = start + span / 2;
         if (max_depth == 0) {
             // two HittableLists; HittableList::BoundingBox folds surroundingBox left to right

@@ -162,6 +162,80 @@ void parallelPieces(size_t n, F fn) {
     for (auto& th : pool) th.join();
 }
 
+// std::sort's permutation, on several threads.  Which of several objects with equal keys ends up first is part of the
+// tree the reference builds (Bvh.h:46 sorts with std::sort, which is not stable), so a faster sort is only usable
+// if it leaves every element exactly where std::sort would.  libstdc++'s std::sort is an introsort: while a range
+// has more than 16 elements, the median of its second, middle and last element is swapped to the front and the
+// rest is partitioned around it from both ends; the right part is handled first (recursively), then the left;
+// after 2 log2(n) levels of that a range is heap-sorted instead; one insertion sort over everything finishes.  The
+// two parts of a partition never exchange elements again -- no element of the right part is smaller than one of
+// the left part, and the final insertion sort only moves an element past strictly larger ones -- so (a) the parts
+// can be sorted by different threads and (b) the final pass is the same as a stable insertion sort of each range
+// of at most 16 elements the partitioning ends with.  The steps below are those of libstdc++ (GCC 4.7 and later;
+// the oracle sorts with the real std::sort, and tests/test_host_flatten.py compares the trees on inputs full of
+// equal keys).
+template <class T, class Less>
+void sortRangeLikeStdSort(T* first, T* last, int depth_limit, Less less, std::atomic<int>& spare_threads) {
+    std::vector<std::thread> helpers;
+    while (last - first > 16) {
+        if (depth_limit == 0) {
+            std::partial_sort(first, last, last, less);  // the heap sort std::sort falls back to
+            break;
+        }
+        depth_limit--;
+        // median of (first + 1, middle, last - 1) to the front
+        T *a = first + 1, *b = first + (last - first) / 2, *c = last - 1;
+        if (less(*a, *b)) {
+            if (less(*b, *c)) std::swap(*first, *b);
+            else if (less(*a, *c)) std::swap(*first, *c);
+            else std::swap(*first, *a);
+        } else if (less(*a, *c)) std::swap(*first, *a);
+        else if (less(*b, *c)) std::swap(*first, *c);
+        else std::swap(*first, *b);
+        // partition of [first + 1, last) around *first, from both ends, without bounds checks (the median's
+        // two companions stop the scans)
+        T *lo = first + 1, *hi = last;
+        for (;;) {
+            while (less(*lo, *first)) ++lo;
+            --hi;
+            while (less(*first, *hi)) --hi;
+            if (!(lo < hi)) break;
+            std::swap(*lo, *hi);
+            ++lo;
+        }
+        T* cut = lo;
+        if (last - cut >= 32768 && spare_threads.fetch_sub(1) > 0) {
+            helpers.emplace_back([=, &spare_threads] { sortRangeLikeStdSort(cut, last, depth_limit, less, spare_threads); });
+        } else {
+            if (last - cut >= 32768) spare_threads.fetch_add(1);  // nothing was taken
+            sortRangeLikeStdSort(cut, last, depth_limit, less, spare_threads);
+        }
+        last = cut;
+    }
+    if (last - first <= 16) {
+        for (T* i = first + 1; i < last; ++i) {
+            T val = *i;
+            T* j = i;
+            while (j > first && less(val, *(j - 1))) {
+                *j = *(j - 1);
+                --j;
+            }
+            *j = val;
+        }
+    }
+    for (std::thread& h : helpers) {
+        h.join();
+        spare_threads.fetch_add(1);
+    }
+}
+template <class T, class Less>
+void sortLikeStdSort(T* first, T* last, Less less, std::atomic<int>& spare_threads) {
+    if (first == last) return;
+    int lg = 0;
+    for (size_t n = (size_t)(last - first); n > 1; n >>= 1) lg++;
+    sortRangeLikeStdSort(first, last, 2 * lg, less, spare_threads);
+}
+
 // Tangent and bitangent of a triangle from its positions (9 floats) and texture coordinates (6 floats):
 //   T = f (dv2 e1 - dv1 e2),  B = f (-du2 e1 + du1 e2),  f = 1 / (du1 dv2 - du2 dv1),
 // e_k = p_k - p_0, (du_k, dv_k) = uv_k - uv_0.  False (and zeros) when the triangle has no texture

@@ -379,3 +379,15 @@ def test_large_mesh_is_taken_in_by_several_threads_as_by_one(rt, orc, scenes, mo
     with pytest.raises(rt.RtError):
         d.add_mesh(rt.IDENTITY, mesh["positions"], bad, m)
     assert d.flatten().n_triangles == 0
+
+
+def test_threaded_sort_leaves_every_element_where_std_sort_does(tmp_path):
+    """The BVH builder sorts ranges of 32,768 objects and more with its own threaded introsort, which must produce
+    std::sort's permutation exactly (equal keys included: their order decides the tree).  tests/sort_check.cpp
+    compares the two directly on inputs full of ties, for 1, 3 and 8 threads."""
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    exe = str(tmp_path / "sort_check")
+    subprocess.run(["g++", "-std=c++17", "-O2", "-pthread", os.path.join(here, "sort_check.cpp"), "-o", exe], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout[-2000:]
