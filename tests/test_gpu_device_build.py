@@ -53,11 +53,16 @@ def test_device_built_structure_of_the_cover_scene(rt, orc, scenes, gpu_ctx, dev
     assert dev_ctx.last_build_ms() > 0
 
 
-def test_device_built_structure_edge_cases(rt, orc, dev_ctx):
-    """One primitive, two, coincident primitives (equal Morton keys are split by position), a mix of
-    spheres and triangles with a huge sphere among small ones."""
+@pytest.mark.parametrize("top", ["default", "1"])
+def test_device_built_structure_edge_cases(rt, orc, dev_ctx, monkeypatch, top):
+    """One primitive, two, coincident primitives (equal Morton keys are split by position), hundreds of coincident
+    ones (the clusters the host splits the top of the tree over all have the same box), a mix of spheres and
+    triangles with a huge sphere among small ones -- with the top of the tree split on the host (the default) and
+    with clustering all the way up (RT_DEVICE_TOP=1)."""
+    if top != "default":
+        monkeypatch.setenv("RT_DEVICE_TOP", top)
     rs = np.random.RandomState(2)
-    for case in ("one", "two", "coincident", "mixed"):
+    for case in ("one", "two", "coincident", "many coincident", "mixed"):
         def build(s):
             m = [s.add_material(0, (0.6, 0.5, 0.4)), s.add_material(1, (0.9, 0.9, 0.9), 0.1), s.add_material(2, (0, 0, 0), 1.5)]
             r = np.random.RandomState(7)
@@ -71,6 +76,12 @@ def test_device_built_structure_edge_cases(rt, orc, dev_ctx):
                     s.add_sphere((0.5, 0.0, 0.0), 1.0, m[i % 3])
                 for i in range(5):
                     s.add_triangle(np.float32([-2, -1, 1.5, 2, -1, 1.5, 0, 2, 1.5]), m[i % 2])
+            elif case == "many coincident":
+                for i in range(300):
+                    s.add_sphere((0.5, 0.0, 0.0), 1.0, m[i % 3])
+                for i in range(260):
+                    s.add_triangle(np.float32([-2, -1, 1.5, 2, -1, 1.5, 0, 2, 1.5]), m[i % 2])
+                s.wrap_bvh()
             else:
                 s.add_sphere((0.0, -1000.0, 0.0), 999.0, m[0])
                 for i in range(300):
