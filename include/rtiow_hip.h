@@ -254,11 +254,11 @@ int rt_set_stream(rt_context* ctx, void* hip_stream);
 int rt_set_reference_traversal(rt_context* ctx, int on);
 
 /* Where later rt_upload_scene() calls build the search structure: on = 1 ON THE DEVICE (csrc/device_bvh.hip:
- * Morton-sorted primitives clustered bottom-up by the surface area of their unions, then the host builder's rule for
- * leaving out inner entries), on = 0 on the host (binned surface-area heuristic, fast_bvh.cpp), on = -1 (the
- * default) on the device for scenes of two million primitives or more that do not carry a host-built structure
- * yet.  The device build takes milliseconds where the host takes seconds (10 M triangles: 15 ms against 3.8 s) and
- * its tree costs about an eighth more per frame.  No counterpart in the reference; the reference-order tree
+ * Morton-sorted primitives clustered bottom-up by the surface area of their unions, the top of the tree split
+ * top-down, then the host builder's rule for leaving out inner entries), on = 0 on the host (binned surface-area
+ * heuristic, fast_bvh.cpp), on = -1 (the default) on the device for scenes of one million primitives or more that
+ * do not carry a host-built structure yet.  The device build takes milliseconds where the host takes seconds
+ * (10 M triangles: 23 ms against 2.7 s) and its tree costs 6 to 8 % more per frame.  No counterpart in the reference; the reference-order tree
  * (BVHNode's constructor, R/src/AccelerationStructures/Bvh.h:18-78, sequential by its use of one random stream
  * and std::sort) is built on the host either way, and images do not depend on this switch (the guard test against
  * the reference's boxes decides every hit).

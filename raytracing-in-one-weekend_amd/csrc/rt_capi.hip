@@ -731,12 +731,12 @@ int rt_upload_scene(rt_context* ctx, rt_scene* s) {
     // With a device-side build the host prepares the reference-order arrays, the guard tables and the
     // builder's inputs only; a scene flattened earlier for a device build gets its host-built structure
     // now if this context wants one.
-    // Left to itself (-1) the context builds on the device from RT_DEVICE_BUILD_MIN primitives up (default 2 M: there the
-    // host build takes seconds and the device-built tree costs about an eighth more per frame; at 1 M it is 0.6 s
-    // against a fifth more), unless the scene already carries a host-built structure from an earlier flatten.
+    // Left to itself (-1) the context builds on the device from RT_DEVICE_BUILD_MIN primitives up (default 1 M: there the
+    // host build takes 0.4 s, at 10 M three seconds, and the device-built tree costs 6 to 8 % more per frame), unless
+    // the scene already carries a host-built structure from an earlier flatten.
     ctx->build_ms = 0.0f;
     const bool hostBuiltAlready = sc.flat.valid && !sc.flat.fast_stale && !sc.flat.fast_nodes.empty();
-    const size_t autoMin = (size_t)std::max(1, envInt("RT_DEVICE_BUILD_MIN", 2000000));
+    const size_t autoMin = (size_t)std::max(1, envInt("RT_DEVICE_BUILD_MIN", 1000000));
     const bool wantDevice = ctx->device_build == 1 ||
                             (ctx->device_build < 0 && !hostBuiltAlready && sc.spheres.size() + sc.triangles.size() >= autoMin);
     PhaseClock clock;
