@@ -484,7 +484,8 @@ static size_t bvhNodeCount(size_t span, int max_depth) {
 // `objs` and its own slots of c.nodes, so the two halves can be built by different threads; the
 // result does not depend on how the work is spread.
 void Scene::buildBvhAt(Composite& c, std::vector<BoxedObj>& objs, size_t start, size_t end, int max_depth, size_t me,
-                       const std::vector<uint8_t>& axes, std::atomic<int>& spare_threads) {
+                       const std::vector<uint8_t>& axes, const std::atomic<size_t>& drawn, std::atomic<int>& spare_threads) {
+    while (drawn.load(std::memory_order_acquire) <= me) std::this_thread::yield();  // (see buildBvh)
     const int axis = axes[me];
     auto less = [axis](const BoxedObj& a, const BoxedObj& b) { return a.box.mn[axis] < b.box.mn[axis]; };
     size_t span = end - start;
@@ -519,14 +520,14 @@ void Scene::buildBvhAt(Composite& c, std::vector<BoxedObj>& objs, size_t start, 
             const size_t l = me + 1;
             const size_t r = l + bvhNodeCount(mid - start, max_depth - 1);
             if (span >= 32768 && spare_threads.fetch_sub(1) > 0) {
-                std::thread other([&] { buildBvhAt(c, objs, start, mid, max_depth - 1, l, axes, spare_threads); });
-                buildBvhAt(c, objs, mid, end, max_depth - 1, r, axes, spare_threads);
+                std::thread other([&] { buildBvhAt(c, objs, start, mid, max_depth - 1, l, axes, drawn, spare_threads); });
+                buildBvhAt(c, objs, mid, end, max_depth - 1, r, axes, drawn, spare_threads);
                 other.join();
                 spare_threads.fetch_add(1);
             } else {
                 if (span >= 32768) spare_threads.fetch_add(1);  // nothing was taken
-                buildBvhAt(c, objs, start, mid, max_depth - 1, l, axes, spare_threads);
-                buildBvhAt(c, objs, mid, end, max_depth - 1, r, axes, spare_threads);
+                buildBvhAt(c, objs, start, mid, max_depth - 1, l, axes, drawn, spare_threads);
+                buildBvhAt(c, objs, mid, end, max_depth - 1, r, axes, drawn, spare_threads);
             }
             c.nodes[me].left = (int)l;
             c.nodes[me].right = (int)r;
@@ -539,12 +540,28 @@ void Scene::buildBvhAt(Composite& c, std::vector<BoxedObj>& objs, size_t start, 
 
 int Scene::buildBvh(Composite& c, std::vector<BoxedObj>& objs, size_t start, size_t end, int max_depth) {
     const size_t total = bvhNodeCount(end - start, max_depth);
-    std::vector<uint8_t> axes(total);
-    for (size_t i = 0; i < total; i++) axes[i] = (uint8_t)randomInt(0, 2);
+    // The draws of a large tree (13 ns each, one thread: the generator is sequential) are made by a thread of their
+    // own while the builders sort; a node waits for its draw if it gets there first, which the top-level sort all
+    // but rules out.  Nobody else touches the generator meanwhile.
     const size_t base = c.nodes.size();
+    std::vector<uint8_t> axes(base + total);  // indexed by node number, like c.nodes
+    std::atomic<size_t> drawn(base);
+    auto draw = [&]() {
+        for (size_t i = 0; i < total; i++) {
+            axes[base + i] = (uint8_t)randomInt(0, 2);
+            if ((i & 8191) == 8191) drawn.store(base + i + 1, std::memory_order_release);
+        }
+        drawn.store(base + total, std::memory_order_release);
+    };
+    std::thread drawer;
+    if (total >= 65536 && buildThreads() > 1)
+        drawer = std::thread(draw);
+    else
+        draw();
     c.nodes.resize(base + total);
     std::atomic<int> spare((int)buildThreads() - 1);
-    buildBvhAt(c, objs, start, end, max_depth, base, axes, spare);
+    buildBvhAt(c, objs, start, end, max_depth, base, axes, drawn, spare);
+    if (drawer.joinable()) drawer.join();
     c.built_first = base;
     c.built_count = total;
     return (int)base;

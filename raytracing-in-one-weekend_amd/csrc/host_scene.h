@@ -313,7 +313,7 @@ private:
     std::vector<BoxedObj> withBoxes(const std::vector<Obj>& objs) const;
     int buildBvh(Composite& c, std::vector<BoxedObj>& objs, size_t start, size_t end, int max_depth);
     void buildBvhAt(Composite& c, std::vector<BoxedObj>& objs, size_t start, size_t end, int max_depth, size_t me,
-                    const std::vector<uint8_t>& axes, std::atomic<int>& spare_threads);
+                    const std::vector<uint8_t>& axes, const std::atomic<size_t>& drawn, std::atomic<int>& spare_threads);
     void emitObjects(const std::vector<Obj>& objs, int parent_entry);
     void emitComposite(const Composite& c);
     void emitBvhNode(const Composite& c, int node);
