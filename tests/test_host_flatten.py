@@ -391,3 +391,27 @@ def test_threaded_sort_leaves_every_element_where_std_sort_does(tmp_path):
     subprocess.run(["g++", "-std=c++17", "-O2", "-pthread", os.path.join(here, "sort_check.cpp"), "-o", exe], check=True)
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout[-2000:]
+
+
+def test_large_tree_with_a_composite_in_a_leaf_is_emitted_the_long_way(rt, orc, scenes):
+    """Large built trees are emitted in pieces only if every leaf holds primitives; a top-level BVH over 70,000
+    spheres and a mesh has one leaf that holds the mesh, so its entries come from the recursive emission -- while
+    nothing of the abandoned attempt may be left behind -- and must be the oracle's all the same."""
+    mesh = scenes.lathe_mesh(6, 4, seed=9)
+
+    def build(s):
+        m = s.add_material(0, (0.5, 0.5, 0.5))
+        rr = np.random.RandomState(23)
+        c = (rr.rand(70000, 3) * 1000).astype(np.float32)
+        rad = (0.5 + 3 * rr.rand(70000)).astype(np.float32)
+        for i in range(35000):
+            s.add_sphere(c[i], float(rad[i]), m)
+        s.add_mesh(scenes.VASE_MODEL, mesh["positions"], mesh["indices"], m, normals=mesh["normals"], uvs=mesh["uvs"], max_depth=2)
+        for i in range(35000, 70000):
+            s.add_sphere(c[i], float(rad[i]), m)
+        s.wrap_bvh()
+
+    a, b = build_both(rt, orc, build)
+    flat = a.get_flat()
+    compare_scene_arrays(flat, b.dump())
+    check_structure(flat, *b.dump_tree())
