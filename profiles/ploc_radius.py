@@ -1,5 +1,5 @@
 """Search radius of the device build's clustering against the frame time of the tree it gives (vase scene, device
-build only).  python profiles/ploc_radius.py <triangles> <radius>[:<top>] [...]"""
+build only).  python profiles/ploc_radius.py <triangles> <radius>[:<top>[:<collapse>]] [...]"""
 import json
 import numpy as np
 import os
@@ -20,10 +20,13 @@ tex = {"diffuse": scenes.noise_texture(1024, 1), "roughness": scenes.noise_textu
 a = rt.Scene()
 scenes.instanced_mesh_scene(a, mesh, copies, tex)
 for radius in sys.argv[2:]:
-    radius, _, top = radius.partition(":")   # "radius" or "radius:clusters the host builds the top over"
+    parts = radius.split(":")   # "radius[:clusters the host builds the top over[:left-out-entry threshold]]"
+    radius = parts[0]
     os.environ["RT_PLOC_RADIUS"] = radius
-    if top:
-        os.environ["RT_DEVICE_TOP"] = top
+    if len(parts) > 1 and parts[1]:
+        os.environ["RT_DEVICE_TOP"] = parts[1]
+    if len(parts) > 2:
+        os.environ["RT_DEVICE_COLLAPSE"] = parts[2]
     ctx = rt.Context(0)
     ctx.set_device_build(True)
     ctx.upload_scene(a)
@@ -43,6 +46,6 @@ for radius in sys.argv[2:]:
     area = d[:, 0] * d[:, 1] + d[:, 1] * d[:, 2] + d[:, 2] * d[:, 0]
     area = area[np.isfinite(area)]
     cost = float(area.sum() / area.max())
-    print(json.dumps({"triangles": copies * mesh["indices"].shape[0], "radius": int(radius), "top": os.environ.get("RT_DEVICE_TOP", "default"), "build_ms": round(ctx.last_build_ms(), 2),
+    print(json.dumps({"triangles": copies * mesh["indices"].shape[0], "radius": int(radius), "top": os.environ.get("RT_DEVICE_TOP", "default"), "collapse": os.environ.get("RT_DEVICE_COLLAPSE", "default"), "build_ms": round(ctx.last_build_ms(), 2),
                       "kernel_ms": [round(t, 2) for t in times], "node_tests_per_ray": round(cnt["node_tests"] / cnt["rays"], 2), "entries": int(ent.shape[0]), "area_cost": round(cost, 2)}), flush=True)
     ctx.close()
