@@ -194,8 +194,8 @@ struct Builder {
             if (mid == start || mid == end) mid = start + n / 2;
         }
         int l, r;
-        if (n >= 32768 && spareThreads.fetch_sub(1) > 0) {
-            std::thread other([&] { l = build(start, mid); });
+        std::thread other;
+        if (n >= 32768 && spareThreads.fetch_sub(1) > 0 && tryThread(other, [&] { l = build(start, mid); })) {
             r = build(mid, end);
             other.join();
             spareThreads.fetch_add(1);
@@ -673,7 +673,10 @@ void Scene::buildFastStructure() {
         };
         std::vector<std::thread> pool;
         const unsigned nThreads = std::min(8u, buildThreads());
-        for (unsigned i = 1; i < nThreads; i++) pool.emplace_back(work);
+        for (unsigned i = 1; i < nThreads; i++) {
+            std::thread th;
+            if (tryThread(th, work)) pool.push_back(std::move(th));
+        }
         work();
         for (auto& t : pool) t.join();
         f.fast_oct.resize((size_t)total * 8);

@@ -519,8 +519,9 @@ void Scene::buildBvhAt(Composite& c, std::vector<BoxedObj>& objs, size_t start, 
         } else {
             const size_t l = me + 1;
             const size_t r = l + bvhNodeCount(mid - start, max_depth - 1);
-            if (span >= 32768 && spare_threads.fetch_sub(1) > 0) {
-                std::thread other([&] { buildBvhAt(c, objs, start, mid, max_depth - 1, l, axes, drawn, spare_threads); });
+            std::thread other;
+            if (span >= 32768 && spare_threads.fetch_sub(1) > 0 &&
+                tryThread(other, [&] { buildBvhAt(c, objs, start, mid, max_depth - 1, l, axes, drawn, spare_threads); })) {
                 buildBvhAt(c, objs, mid, end, max_depth - 1, r, axes, drawn, spare_threads);
                 other.join();
                 spare_threads.fetch_add(1);
@@ -554,10 +555,7 @@ int Scene::buildBvh(Composite& c, std::vector<BoxedObj>& objs, size_t start, siz
         drawn.store(base + total, std::memory_order_release);
     };
     std::thread drawer;
-    if (total >= 65536 && buildThreads() > 1)
-        drawer = std::thread(draw);
-    else
-        draw();
+    if (!(total >= 65536 && buildThreads() > 1 && tryThread(drawer, draw))) draw();
     c.nodes.resize(base + total);
     std::atomic<int> spare((int)buildThreads() - 1);
     buildBvhAt(c, objs, start, end, max_depth, base, axes, drawn, spare);

@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <random>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -144,6 +145,18 @@ struct Camera22 {
 
 unsigned buildThreads();  // threads the host-side builders may use
 
+// Starts fn on a new thread; false, and nothing started, if the system will not give one (the callers then do the
+// work themselves: a limit on threads slows the builders down, it does not stop them)
+template <class F>
+bool tryThread(std::thread& t, F fn) {
+    try {
+        t = std::thread(fn);
+        return true;
+    } catch (const std::system_error&) {
+        return false;
+    }
+}
+
 // fn(first, last) over [0, n) in contiguous pieces on the builders' threads (small ranges: the caller's thread)
 template <class F>
 void parallelPieces(size_t n, F fn) {
@@ -156,7 +169,12 @@ void parallelPieces(size_t n, F fn) {
     std::vector<std::thread> pool;
     for (unsigned t = 1; t < threads; t++) {
         const size_t a = std::min(n, t * piece), b = std::min(n, a + piece);
-        if (a < b) pool.emplace_back([=] { fn(a, b); });
+        if (a >= b) continue;
+        std::thread th;
+        if (tryThread(th, [=] { fn(a, b); }))
+            pool.push_back(std::move(th));
+        else
+            fn(a, b);
     }
     fn((size_t)0, std::min(n, piece));
     for (auto& th : pool) th.join();
@@ -204,10 +222,13 @@ void sortRangeLikeStdSort(T* first, T* last, int depth_limit, Less less, std::at
             ++lo;
         }
         T* cut = lo;
-        if (last - cut >= 32768 && spare_threads.fetch_sub(1) > 0) {
-            helpers.emplace_back([=, &spare_threads] { sortRangeLikeStdSort(cut, last, depth_limit, less, spare_threads); });
+        std::thread helper;
+        const bool wanted = last - cut >= 32768;
+        if (wanted && spare_threads.fetch_sub(1) > 0 &&
+            tryThread(helper, [=, &spare_threads] { sortRangeLikeStdSort(cut, last, depth_limit, less, spare_threads); })) {
+            helpers.push_back(std::move(helper));
         } else {
-            if (last - cut >= 32768) spare_threads.fetch_add(1);  // nothing was taken
+            if (wanted) spare_threads.fetch_add(1);  // nothing was taken
             sortRangeLikeStdSort(cut, last, depth_limit, less, spare_threads);
         }
         last = cut;
